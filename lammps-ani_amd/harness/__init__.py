@@ -1,0 +1,241 @@
+"""Python face of the LAMMPS stand-in harness (``lmp_harness.cpp``) plus synthetic inputs.
+
+Nothing here is on the product path: it fabricates what LAMMPS core would hand to ``PairANI::compute``
+(``src/pair_ani.cpp:70-85`` in the reference) so that tests and ``bench.py`` can drive the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblmpharness.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "lmp_harness.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O3", "-march=x86-64-v3", "-std=c++17", "-fPIC", "-shared", "-o", _SO, src])
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        lib = C.CDLL(_SO)
+        lib.hx_build.restype = C.c_void_p
+        lib.hx_build.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
+        lib.hx_free.argtypes = [C.c_void_p]
+        for name in ("hx_nlocal", "hx_nghost"):
+            getattr(lib, name).restype = C.c_int
+            getattr(lib, name).argtypes = [C.c_void_p]
+        for name in ("hx_x", "hx_type", "hx_tag", "hx_owner_rank", "hx_owner_lidx", "hx_shift", "hx_numneigh", "hx_jlist"):
+            getattr(lib, name).restype = C.c_void_p
+            getattr(lib, name).argtypes = [C.c_void_p]
+        lib.hx_neigh_build.restype = C.c_int64
+        lib.hx_neigh_build.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        lib.hx_set_x.argtypes = [C.c_void_p, C.c_void_p]
+        lib.hx_sub_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _view(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).copy()
+
+
+@dataclass
+class System:
+    """A whole periodic (or open) system before decomposition.  ``types`` are LAMMPS types (1-based)."""
+    x: np.ndarray          # [N,3] float64
+    types: np.ndarray      # [N] int32, 1-based
+    boxlo: np.ndarray      # [3]
+    boxhi: np.ndarray      # [3]
+    periodic: Tuple[bool, bool, bool] = (True, True, True)
+
+    @property
+    def natoms(self) -> int:
+        return len(self.types)
+
+
+@dataclass
+class RankInput:
+    """What one MPI rank's PairANI::compute sees (src/pair_ani.cpp:70-85) + the comm maps LAMMPS keeps."""
+    nlocal: int
+    nghost: int
+    x: np.ndarray            # [ntotal,3] float64
+    types: np.ndarray        # [ntotal] int32 (1-based)
+    tag: np.ndarray          # [ntotal] global index
+    owner_rank: np.ndarray   # [nghost]
+    owner_lidx: np.ndarray   # [nghost]
+    shift: np.ndarray        # [nghost,3]
+    ilist: np.ndarray        # [nlocal] int32 (identity)
+    numneigh: np.ndarray     # [nlocal] int32
+    jlist: np.ndarray        # [npairs] int32, flattened in ilist order
+    half: bool
+
+    @property
+    def ntotal(self) -> int:
+        return self.nlocal + self.nghost
+
+    @property
+    def species(self) -> np.ndarray:
+        """0-based species, ``type - 1`` as src/pair_ani.cpp:110."""
+        return (self.types.astype(np.int64) - 1)
+
+    @property
+    def npairs(self) -> int:
+        return int(self.jlist.shape[0])
+
+    def atom_index12(self) -> np.ndarray:
+        """Half list in the reference layout [0:n]=i, [n:2n]=j (src/pair_ani.cpp:144-145)."""
+        assert self.half
+        i = np.repeat(self.ilist.astype(np.int64), self.numneigh)
+        return np.concatenate([i, self.jlist.astype(np.int64)])
+
+
+def decompose(sys: System, grid=(1, 1, 1), rank: int = 0, cutoff: float = 5.1, skin: float = 2.0,
+              half: bool = False, x_override: Optional[np.ndarray] = None) -> RankInput:
+    """Atoms + ghosts + neighbour list of one rank of a px*py*pz brick decomposition."""
+    lib = _load()
+    x = np.ascontiguousarray(sys.x if x_override is None else x_override, dtype=np.float64)
+    t = np.ascontiguousarray(sys.types, dtype=np.int32)
+    lo = np.ascontiguousarray(sys.boxlo, dtype=np.float64)
+    hi = np.ascontiguousarray(sys.boxhi, dtype=np.float64)
+    per = np.ascontiguousarray(np.array(sys.periodic, dtype=np.int32))
+    cut = cutoff + skin
+    h = lib.hx_build(sys.natoms, x.ctypes.data, t.ctypes.data, lo.ctypes.data, hi.ctypes.data, per.ctypes.data,
+                     grid[0], grid[1], grid[2], rank, cut)
+    try:
+        nl, ng = lib.hx_nlocal(h), lib.hx_nghost(h)
+        nt = nl + ng
+        npairs = lib.hx_neigh_build(h, cut, 1 if half else 0)
+        out = RankInput(
+            nlocal=nl, nghost=ng,
+            x=_view(lib.hx_x(h), nt * 3, np.float64).reshape(nt, 3),
+            types=_view(lib.hx_type(h), nt, np.int32),
+            tag=_view(lib.hx_tag(h), nt, np.int32),
+            owner_rank=_view(lib.hx_owner_rank(h), ng, np.int32),
+            owner_lidx=_view(lib.hx_owner_lidx(h), ng, np.int32),
+            shift=_view(lib.hx_shift(h), ng * 3, np.int32).reshape(ng, 3),
+            ilist=np.arange(nl, dtype=np.int32),
+            numneigh=_view(lib.hx_numneigh(h), nl, np.int32),
+            jlist=_view(lib.hx_jlist(h), npairs, np.int32),
+            half=half)
+    finally:
+        lib.hx_free(h)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# inputs
+# ------------------------------------------------------------------------------------------------------
+
+def read_lammps_data(path: str) -> System:
+    """Minimal reader for ``atom_style atomic`` data files such as tests/golden/water-0.8nm.data."""
+    lo, hi = np.zeros(3), np.zeros(3)
+    rows = []
+    natoms = None
+    section = None
+    with open(path) as f:
+        for line in f:
+            s = line.split("#")[0].strip()
+            if not s:
+                continue
+            tok = s.split()
+            if len(tok) >= 2 and tok[1] == "atoms":
+                natoms = int(tok[0])
+            elif len(tok) == 4 and tok[2] in ("xlo", "ylo", "zlo"):
+                k = "xyz".index(tok[2][0])
+                lo[k], hi[k] = float(tok[0]), float(tok[1])
+            elif tok[0] in ("Masses", "Atoms", "Velocities"):
+                section = tok[0]
+            elif section == "Atoms" and len(tok) >= 5:
+                rows.append((int(tok[0]), int(tok[1]), float(tok[2]), float(tok[3]), float(tok[4])))
+    rows.sort()
+    assert natoms == len(rows), (natoms, len(rows))
+    arr = np.array(rows)
+    return System(arr[:, 2:5].astype(np.float64).copy(), arr[:, 1].astype(np.int32), lo, hi)
+
+
+def water_box(n_atoms: int, seed: int = 12345, density: float = 0.98, type_H: int = 1, type_O: int = 4) -> System:
+    """Synthetic liquid-water-like box: n_atoms/3 rigid waters (r_OH 0.9572 A, 104.52 deg),
+    random orientation, centres on a jittered simple-cubic lattice, density as in
+    examples/benchmark/data/water/prepare/generate_pdb.py:29-48 (0.98 g/cm^3).  Atom order O,H,H per molecule."""
+    assert n_atoms % 3 == 0
+    nmol = n_atoms // 3
+    mass_g = nmol * (15.999 + 2 * 1.008) / 6.0221408e23
+    L = (mass_g / density * 1e24) ** (1.0 / 3.0)
+    rng = np.random.default_rng(seed)
+    ncell = int(np.ceil(nmol ** (1.0 / 3.0)))
+    a = L / ncell
+    idx = rng.permutation(ncell ** 3)[:nmol]
+    ix, iy, iz = idx % ncell, (idx // ncell) % ncell, idx // (ncell * ncell)
+    centres = (np.stack([ix, iy, iz], 1) + 0.5) * a + rng.normal(0.0, 0.25, size=(nmol, 3))
+    # random rotations from normalised quaternions
+    q = rng.normal(size=(nmol, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, xq, yq, zq = q.T
+    R = np.stack([
+        np.stack([1 - 2 * (yq * yq + zq * zq), 2 * (xq * yq - zq * w), 2 * (xq * zq + yq * w)], 1),
+        np.stack([2 * (xq * yq + zq * w), 1 - 2 * (xq * xq + zq * zq), 2 * (yq * zq - xq * w)], 1),
+        np.stack([2 * (xq * zq - yq * w), 2 * (yq * zq + xq * w), 1 - 2 * (xq * xq + yq * yq)], 1)], 1)
+    roh, ang = 0.9572, np.deg2rad(104.52)
+    h1 = np.array([roh * np.sin(ang / 2), roh * np.cos(ang / 2), 0.0])
+    h2 = np.array([-roh * np.sin(ang / 2), roh * np.cos(ang / 2), 0.0])
+    pos = np.empty((nmol, 3, 3))
+    pos[:, 0] = centres
+    pos[:, 1] = centres + R @ h1
+    pos[:, 2] = centres + R @ h2
+    x = pos.reshape(-1, 3) - L / 2
+    types = np.tile(np.array([type_O, type_H, type_H], dtype=np.int32), nmol)
+    lo, hi = np.full(3, -L / 2), np.full(3, L / 2)
+    x = lo + np.mod(x - lo, L)
+    return System(x, types, lo, hi)
+
+
+def random_box(n_atoms: int, ntypes: int, L: float, seed: int = 7, min_dist: float = 0.9) -> System:
+    """Mixed-species random box (rejection on a minimum distance) — exercises every species bucket."""
+    rng = np.random.default_rng(seed)
+    pts = []
+    cell = {}
+    inv = 1.0 / min_dist
+    ncell = max(1, int(L * inv))
+
+    def key(p):
+        return tuple((np.floor(p * ncell / L).astype(int)) % ncell)
+
+    tries = 0
+    while len(pts) < n_atoms and tries < 200 * n_atoms:
+        tries += 1
+        p = rng.uniform(0, L, 3)
+        k = key(p)
+        ok = True
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    kk = ((k[0] + dx) % ncell, (k[1] + dy) % ncell, (k[2] + dz) % ncell)
+                    for q in cell.get(kk, ()):
+                        dd = p - q
+                        dd -= L * np.round(dd / L)
+                        if dd @ dd < min_dist * min_dist:
+                            ok = False
+        if ok:
+            pts.append(p)
+            cell.setdefault(k, []).append(p)
+    assert len(pts) == n_atoms, "box too dense for min_dist"
+    x = np.array(pts) - L / 2
+    types = rng.integers(1, ntypes + 1, size=n_atoms).astype(np.int32)
+    return System(x, types, np.full(3, -L / 2), np.full(3, L / 2))

@@ -1,0 +1,486 @@
+/*
+ * ani_oracle.c — CPU restatement of the lammps-ani per-step hot path.   TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (lammps-ani_amd/csrc, libani_hip.so) never links, calls or falls back to it.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in the un-vendored submodule external/torchani
+ * (reference .gitmodules:15-17, empty directory in /root/reference) and the trained ANI-2x parameters are
+ * not in the container, so none of the reference's golden vectors (src/ani_csrc/test_model.cpp:84-137,
+ * tests/lammps-unittest/test_ani2x_nocuaev_double_half, the five fp64 yaml files) can be evaluated.  What pins this file instead:
+ * an independent torch-autograd restatement of the same published algorithm (tests/golden/make_golden.py,
+ * fixtures committed under tests/golden/), central finite differences, and invariance properties.
+ *
+ * What is restated, and where the reference defines it:
+ *   - dataflow / units / ghost handling:      models/lammps_ani.py:130-216, src/ani_csrc/ani.cpp:183-265
+ *   - full list -> pairs, centre = ilist[ii]: models/lammps_ani.py:156-166, src/pair_ani.cpp:129-150
+ *   - half list (atom_index12 [2][npairs]):   src/ani_csrc/ani.cpp:100-180, src/pair_ani.cpp:141-146
+ *   - AEV (pyaev = torchani AEVComputer):     call sites models/lammps_ani.py:277-296; functional form from
+ *       the ANI-1 paper (Smith, Isayev, Roitberg, Chem. Sci. 2017) and torchani's public aev.py:
+ *       radial  0.25*exp(-EtaR (r-ShfR)^2) * fc(r;Rcr);  fc(r;Rc) = 0.5 cos(pi r/Rc) + 0.5
+ *       angular 2*((1+cos(theta-ShfZ))/2)^Zeta * exp(-EtaA((rj+rk)/2-ShfA)^2) * fc(rj;Rca) fc(rk;Rca),
+ *               theta = acos(0.95 cos_jk), one term per unordered neighbour pair
+ *   - NN ensemble (BmmEnsemble, CELU 0.1, mean over members) + energy_shifter: models/lammps_ani.py:218-257
+ *   - forces = -dE/dx on local AND ghost atoms, virial = -sym(sum_pairs dE/d(diff) x diff):
+ *                                             models/lammps_ani.py:195-216
+ *   - Hartree -> kcal/mol (627.5094738898777): src/ani_csrc/ani.h:9, ani.cpp:246-262
+ *
+ * radial_compat = 0 ("cuaev" behaviour): a list pair contributes to the radial AEV only if r <= Rcr.
+ * radial_compat = 1 ("pyaev" behaviour): every list pair contributes, the cosine
+ *                    cutoff being evaluated past Rcr exactly as torchani's CutoffCosine does
+ *                    ("assuming all elements in distances are smaller than cutoff").
+ * The angular part screens r <= Rca in both modes.
+ *
+ * REAL is double (libani_oracle64.so) or float (libani_oracle32.so); energy / virial sums are always double.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef REAL
+#define REAL double
+#endif
+
+#define HARTREE2KCALMOL 627.5094738898777
+#define MAXL 8
+#define MAXS 16
+
+typedef struct {
+  int S, M, L, nR, nA, nZ;
+  double Rcr, Rca, EtaR, EtaA, Zeta, alpha;
+  double *ShfR, *ShfA, *ShfZ;
+  double sae[MAXS];
+  int dims[MAXS][MAXL + 1];
+  REAL* W[64][MAXS][MAXL]; /* [m][s][l] -> [out][in] */
+  REAL* B[64][MAXS][MAXL];
+  int radial_len, angular_len, aev_len;
+  int triu[MAXS][MAXS];
+  char err[256];
+} oracle_model;
+
+static int rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n ? 0 : -1; }
+
+void ani_oracle_free(oracle_model* m) {
+  if (!m) return;
+  free(m->ShfR);
+  free(m->ShfA);
+  free(m->ShfZ);
+  for (int a = 0; a < 64; a++)
+    for (int s = 0; s < MAXS; s++)
+      for (int l = 0; l < MAXL; l++) {
+        free(m->W[a][s][l]);
+        free(m->B[a][s][l]);
+      }
+  free(m);
+}
+
+/* model file layout: lammps-ani_amd/model_file.py */
+oracle_model* ani_oracle_load(const char* path, int use_num_models) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return NULL;
+  oracle_model* m = (oracle_model*)calloc(1, sizeof(oracle_model));
+  char magic[8];
+  uint32_t h[6];
+  double c[6];
+  if (rd(f, magic, 8) || memcmp(magic, "ANIHIP01", 8) || rd(f, h, 24) || rd(f, c, 48)) goto fail;
+  m->S = h[0]; m->M = h[1]; m->L = h[2]; m->nR = h[3]; m->nA = h[4]; m->nZ = h[5];
+  if (m->S > MAXS || m->L > MAXL || m->M > 64) goto fail;
+  m->Rcr = c[0]; m->Rca = c[1]; m->EtaR = c[2]; m->EtaA = c[3]; m->Zeta = c[4]; m->alpha = c[5];
+  m->ShfR = (double*)malloc(8 * m->nR);
+  m->ShfA = (double*)malloc(8 * m->nA);
+  m->ShfZ = (double*)malloc(8 * m->nZ);
+  if (rd(f, m->ShfR, 8 * m->nR) || rd(f, m->ShfA, 8 * m->nA) || rd(f, m->ShfZ, 8 * m->nZ)) goto fail;
+  for (int s = 0; s < m->S; s++) {
+    char sym[4];
+    uint32_t d[MAXL + 1];
+    if (rd(f, sym, 4) || rd(f, &m->sae[s], 8) || rd(f, d, 4 * (m->L + 1))) goto fail;
+    for (int l = 0; l <= m->L; l++) m->dims[s][l] = (int)d[l];
+  }
+  int Mfile = m->M;
+  if (use_num_models < 0) use_num_models = Mfile;
+  if (use_num_models < 1 || use_num_models > Mfile) goto fail;
+  for (int a = 0; a < Mfile; a++)
+    for (int s = 0; s < m->S; s++)
+      for (int l = 0; l < m->L; l++) {
+        size_t o = m->dims[s][l + 1], i = m->dims[s][l];
+        float* w = (float*)malloc(4 * o * i);
+        float* b = (float*)malloc(4 * o);
+        if (rd(f, w, 4 * o * i) || rd(f, b, 4 * o)) { free(w); free(b); goto fail; }
+        if (a < use_num_models) { /* first-n members: models/lammps_ani.py:342 */
+          m->W[a][s][l] = (REAL*)malloc(sizeof(REAL) * o * i);
+          m->B[a][s][l] = (REAL*)malloc(sizeof(REAL) * o);
+          for (size_t k = 0; k < o * i; k++) m->W[a][s][l][k] = (REAL)w[k];
+          for (size_t k = 0; k < o; k++) m->B[a][s][l][k] = (REAL)b[k];
+        }
+        free(w);
+        free(b);
+      }
+  m->M = use_num_models;
+  fclose(f);
+  m->radial_len = m->S * m->nR;
+  m->angular_len = m->S * (m->S + 1) / 2 * m->nA * m->nZ;
+  m->aev_len = m->radial_len + m->angular_len;
+  { /* row-major upper triangle incl. diagonal, symmetric lookup (torchani triu_index) */
+    int p = 0;
+    for (int a = 0; a < m->S; a++)
+      for (int b = a; b < m->S; b++) { m->triu[a][b] = p; m->triu[b][a] = p; p++; }
+  }
+  return m;
+fail:
+  fclose(f);
+  ani_oracle_free(m);
+  return NULL;
+}
+
+int ani_oracle_aev_len(const oracle_model* m) { return m->aev_len; }
+int ani_oracle_num_models(const oracle_model* m) { return m->M; }
+int ani_oracle_real_bytes(void) { return (int)sizeof(REAL); }
+
+/* ------------------------------------------------------------------------------------------------ */
+
+static inline REAL fcut(REAL r, REAL Rc) { return (REAL)0.5 * (REAL)cos((double)(r * ((REAL)M_PI / Rc))) + (REAL)0.5; }
+static inline REAL dfcut(REAL r, REAL Rc) { return (REAL)-0.5 * ((REAL)M_PI / Rc) * (REAL)sin((double)(r * ((REAL)M_PI / Rc))); }
+
+typedef struct { int j; int sp; REAL d[3]; REAL r; } nbr_t;
+
+/* gather the neighbours of centre i from CSR; returns count.  rad[] flags radial inclusion, ang[] angular */
+static int gather(const oracle_model* m, int i, const int64_t* species, const double* x, const int64_t* off,
+                  const int* nj, int compat, nbr_t* nb, char* rad, char* ang) {
+  int n = 0;
+  for (int64_t p = off[0]; p < off[1]; p++) {
+    int j = nj[p];
+    nbr_t* q = &nb[n];
+    /* positions are cast to REAL before differencing, as coordinates.to(dtype) does (ani.cpp:206-207) */
+    for (int c = 0; c < 3; c++) q->d[c] = (REAL)x[3 * j + c] - (REAL)x[3 * i + c];
+    q->r = (REAL)sqrt((double)(q->d[0] * q->d[0] + q->d[1] * q->d[1] + q->d[2] * q->d[2]));
+    q->j = j;
+    q->sp = (int)species[j];
+    rad[n] = compat ? 1 : (q->r <= (REAL)m->Rcr);
+    ang[n] = (q->r <= (REAL)m->Rca);
+    n++;
+  }
+  return n;
+}
+
+static void aev_forward(const oracle_model* m, int n, const nbr_t* nb, const char* rad, const char* ang, REAL* aev) {
+  const int nR = m->nR, nA = m->nA, nZ = m->nZ;
+  for (int k = 0; k < m->aev_len; k++) aev[k] = 0;
+  for (int p = 0; p < n; p++) {
+    if (!rad[p]) continue;
+    REAL r = nb[p].r, fc = fcut(r, (REAL)m->Rcr);
+    REAL* out = aev + nb[p].sp * nR;
+    for (int k = 0; k < nR; k++) {
+      REAL dr = r - (REAL)m->ShfR[k];
+      out[k] += (REAL)0.25 * (REAL)exp((double)(-(REAL)m->EtaR * dr * dr)) * fc;
+    }
+  }
+  for (int p = 0; p < n; p++) {
+    if (!ang[p]) continue;
+    for (int q = p + 1; q < n; q++) {
+      if (!ang[q]) continue;
+      const nbr_t *a = &nb[p], *b = &nb[q];
+      REAL dot = a->d[0] * b->d[0] + a->d[1] * b->d[1] + a->d[2] * b->d[2];
+      REAL rr = a->r * b->r;
+      if (rr < (REAL)1e-10) rr = (REAL)1e-10;
+      REAL theta = (REAL)acos((double)((REAL)0.95 * dot / rr));
+      REAL P = fcut(a->r, (REAL)m->Rca) * fcut(b->r, (REAL)m->Rca);
+      REAL rho = (a->r + b->r) * (REAL)0.5;
+      REAL* out = aev + m->radial_len + m->triu[a->sp][b->sp] * nA * nZ;
+      for (int ia = 0; ia < nA; ia++) {
+        REAL dr = rho - (REAL)m->ShfA[ia];
+        REAL f2 = (REAL)exp((double)(-(REAL)m->EtaA * dr * dr));
+        for (int iz = 0; iz < nZ; iz++) {
+          REAL f1 = (REAL)pow((double)(((REAL)1 + (REAL)cos((double)(theta - (REAL)m->ShfZ[iz]))) * (REAL)0.5), m->Zeta);
+          out[ia * nZ + iz] += (REAL)2 * f1 * f2 * P;
+        }
+      }
+    }
+  }
+}
+
+/* given g = dE/dAEV of this centre, accumulate gd[p][3] = dE/d(d_p) for every neighbour p */
+static void aev_backward(const oracle_model* m, int n, const nbr_t* nb, const char* rad, const char* ang, const REAL* g, REAL (*gd)[3]) {
+  const int nR = m->nR, nA = m->nA, nZ = m->nZ;
+  for (int p = 0; p < n; p++) gd[p][0] = gd[p][1] = gd[p][2] = 0;
+  for (int p = 0; p < n; p++) {
+    if (!rad[p]) continue;
+    REAL r = nb[p].r, fc = fcut(r, (REAL)m->Rcr), dfc = dfcut(r, (REAL)m->Rcr);
+    const REAL* gg = g + nb[p].sp * nR;
+    REAL dEdr = 0;
+    for (int k = 0; k < nR; k++) {
+      REAL dr = r - (REAL)m->ShfR[k];
+      REAL e = (REAL)0.25 * (REAL)exp((double)(-(REAL)m->EtaR * dr * dr));
+      dEdr += gg[k] * (e * dfc - (REAL)2 * (REAL)m->EtaR * dr * e * fc);
+    }
+    for (int c = 0; c < 3; c++) gd[p][c] += dEdr * nb[p].d[c] / r;
+  }
+  for (int p = 0; p < n; p++) {
+    if (!ang[p]) continue;
+    for (int q = p + 1; q < n; q++) {
+      if (!ang[q]) continue;
+      const nbr_t *a = &nb[p], *b = &nb[q];
+      REAL dot = a->d[0] * b->d[0] + a->d[1] * b->d[1] + a->d[2] * b->d[2];
+      REAL rr = a->r * b->r;
+      REAL cosv = dot / rr;
+      REAL cp = (REAL)0.95 * cosv;
+      REAL theta = (REAL)acos((double)cp);
+      REAL sint = (REAL)sqrt((double)((REAL)1 - cp * cp));
+      REAL fca = fcut(a->r, (REAL)m->Rca), fcb = fcut(b->r, (REAL)m->Rca);
+      REAL dfa = dfcut(a->r, (REAL)m->Rca), dfb = dfcut(b->r, (REAL)m->Rca);
+      REAL P = fca * fcb, rho = (a->r + b->r) * (REAL)0.5;
+      const REAL* gg = g + m->radial_len + m->triu[a->sp][b->sp] * nA * nZ;
+      /* A: dE/dcos(theta) ; Bq: dE/drho ; C: sum g*2*f1*f2 (multiplies d(fca fcb)) */
+      REAL A = 0, Bq = 0, C = 0;
+      for (int ia = 0; ia < nA; ia++) {
+        REAL dr = rho - (REAL)m->ShfA[ia];
+        REAL f2 = (REAL)exp((double)(-(REAL)m->EtaA * dr * dr));
+        REAL df2 = (REAL)-2 * (REAL)m->EtaA * dr * f2;
+        for (int iz = 0; iz < nZ; iz++) {
+          REAL ph = theta - (REAL)m->ShfZ[iz];
+          REAL base = ((REAL)1 + (REAL)cos((double)ph)) * (REAL)0.5;
+          REAL f1 = (REAL)pow((double)base, m->Zeta);
+          /* d f1 / d cp = Zeta * base^(Zeta-1) * 0.5 * sin(theta - ShfZ)/sin(theta) */
+          REAL df1 = (REAL)m->Zeta * (REAL)pow((double)base, m->Zeta - 1.0) * (REAL)0.5 * (REAL)sin((double)ph) / sint;
+          REAL gv = gg[ia * nZ + iz];
+          A += gv * (REAL)2 * P * f2 * df1 * (REAL)0.95;
+          Bq += gv * (REAL)2 * P * f1 * df2;
+          C += gv * (REAL)2 * f1 * f2;
+        }
+      }
+      for (int c = 0; c < 3; c++) {
+        REAL ua = a->d[c] / a->r, ub = b->d[c] / b->r;
+        gd[p][c] += A * (b->d[c] / rr - cosv * a->d[c] / (a->r * a->r)) + (Bq * (REAL)0.5 + C * dfa * fcb) * ua;
+        gd[q][c] += A * (a->d[c] / rr - cosv * b->d[c] / (b->r * b->r)) + (Bq * (REAL)0.5 + C * fca * dfb) * ub;
+      }
+    }
+  }
+}
+
+static inline REAL celu(REAL z, REAL alpha) { return z > 0 ? z : alpha * ((REAL)exp((double)(z / alpha)) - (REAL)1); }
+static inline REAL dcelu_from_h(REAL h, REAL alpha) { return h > 0 ? (REAL)1 : h / alpha + (REAL)1; }
+
+/* one network (member a, species s) on a block of nb atoms: rows X[nb][in0] -> e[nb] (added), G[nb][in0] (added, scaled) */
+static void mlp_block(const oracle_model* m, int a, int s, int nb, const REAL* X, int ldx, REAL scale, double* e, REAL* G, REAL* work) {
+  const int L = m->L;
+  const int* d = m->dims[s];
+  int maxw = 0;
+  for (int l = 0; l <= L; l++) if (d[l] > maxw) maxw = d[l];
+  /* activations H[l] for l=1..L-1 stored in work; layout [l][nb][maxw] */
+  REAL* H = work;
+  REAL* Gcur = work + (size_t)(L + 1) * nb * maxw;
+  REAL* Gnext = Gcur + (size_t)nb * maxw;
+  const REAL alpha = (REAL)m->alpha;
+  for (int l = 0; l < L; l++) {
+    const REAL* Wl = m->W[a][s][l];
+    const REAL* Bl = m->B[a][s][l];
+    const int in = d[l], out = d[l + 1];
+    for (int o = 0; o < out; o++) {
+      const REAL* w = Wl + (size_t)o * in;
+      for (int t = 0; t < nb; t++) {
+        const REAL* h = (l == 0) ? X + (size_t)t * ldx : H + ((size_t)l * nb + t) * maxw;
+        REAL acc = 0;
+#pragma omp simd reduction(+ : acc)
+        for (int i = 0; i < in; i++) acc += w[i] * h[i];
+        acc += Bl[o];
+        H[((size_t)(l + 1) * nb + t) * maxw + o] = (l == L - 1) ? acc : celu(acc, alpha);
+      }
+    }
+  }
+  for (int t = 0; t < nb; t++) e[t] += (double)scale * (double)H[((size_t)L * nb + t) * maxw + 0];
+  /* backward: dE/d(out of last layer) = scale */
+  for (int t = 0; t < nb; t++) Gcur[(size_t)t * maxw] = scale;
+  for (int l = L - 1; l >= 0; l--) {
+    const REAL* Wl = m->W[a][s][l];
+    const int in = d[l], out = d[l + 1];
+    for (int t = 0; t < nb; t++) {
+      REAL* gi = (l == 0) ? G + (size_t)t * ldx : Gnext + (size_t)t * maxw;
+      if (l != 0) for (int i = 0; i < in; i++) gi[i] = 0;
+      const REAL* go = Gcur + (size_t)t * maxw;
+      for (int o = 0; o < out; o++) {
+        const REAL gv = go[o];
+        const REAL* w = Wl + (size_t)o * in;
+#pragma omp simd
+        for (int i = 0; i < in; i++) gi[i] += gv * w[i];
+      }
+      if (l != 0) { /* through celu of layer l-1's output */
+        const REAL* h = H + ((size_t)l * nb + t) * maxw;
+        for (int i = 0; i < in; i++) gi[i] *= dcelu_from_h(h[i], alpha);
+      }
+    }
+    REAL* tmp = Gcur; Gcur = Gnext; Gnext = tmp;
+  }
+}
+
+/*
+ * Core: centres given as CSR (centre atom index, neighbour offsets into nj).
+ * Outputs (any may be NULL except energy, force): energy [1] kcal/mol, force [ntotal*3] kcal/mol/A (overwritten),
+ * eatom [ncentre] kcal/mol (in centre order), virial [9] kcal/mol row-major, aev_out [ncentre*aev_len],
+ * gaev_out [ncentre*aev_len] (dE/dAEV in Hartree).
+ */
+static int compute_core(const oracle_model* m, int ntotal, int ncentre, const int* centre, const int64_t* off, const int* nj,
+                        const int64_t* species, const double* x, int compat, double* energy, double* force, double* eatom,
+                        double* virial, REAL* aev_out, REAL* gaev_out) {
+  const int A = m->aev_len;
+  int maxn = 0;
+  for (int c = 0; c < ncentre; c++) { int n = (int)(off[c + 1] - off[c]); if (n > maxn) maxn = n; }
+  for (int c = 0; c < ncentre; c++) { int s = (int)species[centre[c]]; if (s < 0 || s >= m->S) return -2; }
+  REAL* aev = aev_out ? aev_out : (REAL*)malloc(sizeof(REAL) * (size_t)ncentre * A);
+  REAL* gaev = gaev_out ? gaev_out : (REAL*)malloc(sizeof(REAL) * (size_t)ncentre * A);
+  double* ea = (double*)calloc(ncentre > 0 ? ncentre : 1, sizeof(double));
+  if (!aev || !gaev || !ea) return -1;
+  memset(gaev, 0, sizeof(REAL) * (size_t)ncentre * A);
+
+  /* pass A: AEV of every centre */
+#pragma omp parallel
+  {
+    nbr_t* nb = (nbr_t*)malloc(sizeof(nbr_t) * (maxn + 1));
+    char* rad = (char*)malloc(maxn + 1);
+    char* ang = (char*)malloc(maxn + 1);
+#pragma omp for schedule(dynamic, 16)
+    for (int c = 0; c < ncentre; c++) {
+      int n = gather(m, centre[c], species, x, off + c, nj, compat, nb, rad, ang);
+      aev_forward(m, n, nb, rad, ang, aev + (size_t)c * A);
+    }
+    free(nb); free(rad); free(ang);
+  }
+
+  /* pass B: species-bucketed MLP ensemble forward + input-gradient backward (BmmEnsemble: mean over members) */
+  enum { NB = 16 };
+  int maxw = A;
+  for (int s = 0; s < m->S; s++) for (int l = 0; l <= m->L; l++) if (m->dims[s][l] > maxw) maxw = m->dims[s][l];
+  for (int s = 0; s < m->S; s++) {
+    int* idx = (int*)malloc(sizeof(int) * (ncentre > 0 ? ncentre : 1));
+    int ns = 0;
+    for (int c = 0; c < ncentre; c++) if ((int)species[centre[c]] == s) idx[ns++] = c;
+    int nblk = (ns + NB - 1) / NB;
+#pragma omp parallel
+    {
+      REAL* X = (REAL*)malloc(sizeof(REAL) * (size_t)NB * A);
+      REAL* G = (REAL*)malloc(sizeof(REAL) * (size_t)NB * A);
+      REAL* work = (REAL*)malloc(sizeof(REAL) * (size_t)(m->L + 3) * NB * maxw);
+      double eb[NB];
+#pragma omp for schedule(dynamic, 1)
+      for (int b = 0; b < nblk; b++) {
+        int nb = ns - b * NB < NB ? ns - b * NB : NB;
+        for (int t = 0; t < nb; t++) memcpy(X + (size_t)t * A, aev + (size_t)idx[b * NB + t] * A, sizeof(REAL) * A);
+        memset(G, 0, sizeof(REAL) * (size_t)NB * A);
+        for (int t = 0; t < nb; t++) eb[t] = 0;
+        for (int a = 0; a < m->M; a++) mlp_block(m, a, s, nb, X, A, (REAL)1 / (REAL)m->M, eb, G, work);
+        for (int t = 0; t < nb; t++) {
+          int c = idx[b * NB + t];
+          ea[c] = eb[t] + m->sae[s]; /* energy_shifter: models/lammps_ani.py:230,250 */
+          memcpy(gaev + (size_t)c * A, G + (size_t)t * A, sizeof(REAL) * A);
+        }
+      }
+      free(X); free(G); free(work);
+    }
+    free(idx);
+  }
+
+  /* pass C: AEV backward -> forces on local and ghost atoms, virial */
+  double etot = 0;
+  for (int c = 0; c < ncentre; c++) etot += ea[c];
+  memset(force, 0, sizeof(double) * 3 * (size_t)ntotal);
+  double vir[9] = {0};
+#pragma omp parallel
+  {
+    nbr_t* nb = (nbr_t*)malloc(sizeof(nbr_t) * (maxn + 1));
+    char* rad = (char*)malloc(maxn + 1);
+    char* ang = (char*)malloc(maxn + 1);
+    REAL(*gd)[3] = (REAL(*)[3])malloc(sizeof(REAL) * 3 * (maxn + 1));
+    double v[9] = {0};
+#pragma omp for schedule(dynamic, 16)
+    for (int c = 0; c < ncentre; c++) {
+      int i = centre[c];
+      int n = gather(m, i, species, x, off + c, nj, compat, nb, rad, ang);
+      aev_backward(m, n, nb, rad, ang, gaev + (size_t)c * A, gd);
+      double fi[3] = {0, 0, 0};
+      for (int p = 0; p < n; p++) {
+        for (int k = 0; k < 3; k++) {
+          double gk = (double)gd[p][k] * HARTREE2KCALMOL;
+          fi[k] += gk; /* d_p = x_j - x_i : dE/dx_i = -sum gd, F_i = +sum gd */
+#pragma omp atomic
+          force[3 * nb[p].j + k] -= gk;
+          /* virial = -sym( dEdR^T diff ), diff = x_i - x_j = -d_p, dEdR = -gd  (models/lammps_ani.py:199-200,215) */
+          for (int l = 0; l < 3; l++) v[3 * k + l] -= gk * (double)nb[p].d[l];
+        }
+      }
+      for (int k = 0; k < 3; k++) {
+#pragma omp atomic
+        force[3 * i + k] += fi[k];
+      }
+    }
+#pragma omp critical
+    for (int k = 0; k < 9; k++) vir[k] += v[k];
+    free(nb); free(rad); free(ang); free(gd);
+  }
+  *energy = etot * HARTREE2KCALMOL;
+  if (eatom) for (int c = 0; c < ncentre; c++) eatom[c] = ea[c] * HARTREE2KCALMOL;
+  if (virial)
+    for (int k = 0; k < 3; k++)
+      for (int l = 0; l < 3; l++) virial[3 * k + l] = 0.5 * (vir[3 * k + l] + vir[3 * l + k]);
+  if (!aev_out) free(aev);
+  if (!gaev_out) free(gaev);
+  free(ea);
+  return 0;
+}
+
+/*
+ * Full neighbour list entry (mirrors ANI::compute, src/ani_csrc/ani.cpp:183-265 + models/lammps_ani.py:156-166):
+ * ilist[nlocal] centre atoms, numneigh[nlocal] and jlist flattened IN ilist ORDER (src/pair_ani.cpp:129-150).
+ * eatom is returned indexed by centre position ii (the reference returns atomic_energies[:, :nlocal], which
+ * coincides when ilist is the identity).
+ */
+int ani_oracle_compute_full(const oracle_model* m, int ntotal, int nlocal, const int64_t* species, const double* x,
+                            const int* ilist, const int* numneigh, const int* jlist, int radial_compat, double* energy,
+                            double* force, double* eatom, double* virial, REAL* aev_out, REAL* gaev_out) {
+  int64_t* off = (int64_t*)malloc(sizeof(int64_t) * (nlocal + 1));
+  off[0] = 0;
+  for (int c = 0; c < nlocal; c++) off[c + 1] = off[c] + numneigh[c];
+  int rc = compute_core(m, ntotal, nlocal, ilist, off, jlist, species, x, radial_compat, energy, force, eatom, virial, aev_out, gaev_out);
+  free(off);
+  return rc;
+}
+
+/*
+ * Half neighbour list entry (mirrors ANI::compute half overload, src/ani_csrc/ani.cpp:100-180):
+ * atom_index12 laid out [0:n]=i, [n:2n]=j (src/pair_ani.cpp:144-145).  Every atom < nlocal is a centre
+ * (species_ghost_as_padding[:, nlocal:] = -1, ani.cpp:151-153); a pair feeds both of its local ends.
+ */
+int ani_oracle_compute_half(const oracle_model* m, int ntotal, int nlocal, const int64_t* species, const double* x, int64_t npairs,
+                            const int64_t* atom_index12, int radial_compat, double* energy, double* force, double* eatom,
+                            double* virial, REAL* aev_out, REAL* gaev_out) {
+  int64_t* off = (int64_t*)calloc(nlocal + 2, sizeof(int64_t));
+  for (int64_t p = 0; p < npairs; p++) {
+    int64_t a = atom_index12[p], b = atom_index12[npairs + p];
+    if (a < nlocal) off[a + 1]++;
+    if (b < nlocal) off[b + 1]++;
+  }
+  for (int c = 0; c < nlocal; c++) off[c + 1] += off[c];
+  int* nj = (int*)malloc(sizeof(int) * (off[nlocal] > 0 ? off[nlocal] : 1));
+  int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * (nlocal + 1));
+  memcpy(fill, off, sizeof(int64_t) * (nlocal + 1));
+  for (int64_t p = 0; p < npairs; p++) {
+    int64_t a = atom_index12[p], b = atom_index12[npairs + p];
+    if (a < nlocal) nj[fill[a]++] = (int)b;
+    if (b < nlocal) nj[fill[b]++] = (int)a;
+  }
+  int* centre = (int*)malloc(sizeof(int) * (nlocal > 0 ? nlocal : 1));
+  for (int c = 0; c < nlocal; c++) centre[c] = c;
+  int rc = compute_core(m, ntotal, nlocal, centre, off, nj, species, x, radial_compat, energy, force, eatom, virial, aev_out, gaev_out);
+  free(off); free(nj); free(fill); free(centre);
+  return rc;
+}
+
+int ani_oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
