@@ -1,0 +1,130 @@
+/*
+ * ani_hip.h — C ABI of libani_hip.so, the MI355X (gfx950) implementation of the lammps-ani hot path.
+ *
+ * This is the drop-in boundary: it replaces the reference's libtorch shim `class ANI`
+ * (src/ani_csrc/ani.h:11-85, src/ani_csrc/ani.cpp) and everything beneath it (TorchScript LammpsANI wrapper,
+ * torchani cuaev/pyaev, BmmEnsemble).  Plain pointers and sizes only; no C++ or torch types cross it; no
+ * exceptions cross it (nonzero return + ani_last_error()).  The LAMMPS-side adapter
+ * (lammps-ani_amd/csrc/pair_ani.cpp) and the python binding (lammps-ani_amd/ani_hip.py) both sit on this header.
+ *
+ * Units at the boundary are the reference's (src/ani_csrc/ani.cpp:246-262): energies kcal/mol, forces
+ * kcal/mol/Angstrom, virial kcal/mol, coordinates Angstrom.
+ *
+ * There is NO cpu device in this library: local_rank < 0 (the reference's `device cpu`) is refused with an
+ * error, and nothing here falls back to host arithmetic.
+ */
+#ifndef ANI_HIP_H
+#define ANI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ani_handle ani_handle;
+
+/* src/ani_csrc/ani.h:9 */
+#define ANI_HARTREE2KCALMOL 627.5094738898777
+
+/* return codes */
+#define ANI_OK 0
+#define ANI_ERR_ARG 1      /* bad argument / unsupported option */
+#define ANI_ERR_MODEL 2    /* model file unreadable or malformed */
+#define ANI_ERR_DEVICE 3   /* HIP runtime error, no device */
+#define ANI_ERR_CAPACITY 4 /* a per-atom neighbour count exceeded the kernels' LDS capacity */
+
+/*
+ * Replaces ANI::ANI(model_file, local_rank, use_num_models, use_cuaev, use_fullnbr, use_single)
+ * (src/ani_csrc/ani.h:31-36, src/ani_csrc/ani.cpp:35-97).
+ *   model_file      flat model file (lammps-ani_amd/model_file.py), not a TorchScript archive
+ *   local_rank      HIP device ordinal (the reference maps node-local rank % device count, src/pair_ani.cpp:255-283);
+ *                   -1 = cpu is refused
+ *   use_num_models  first n ensemble members, -1 = all (models/lammps_ani.py:332-343)
+ *   use_cuaev       1: radial terms screened at Rcr (cuaev behaviour); 0: "pyaev" behaviour, every list pair
+ *                   contributes with the cosine cutoff evaluated past Rcr.
+ *                   Unlike the reference (models/lammps_ani.py:151-153,211) the virial is computed in both modes.
+ *   use_fullnbr     1: ani_compute_full will be used, 0: ani_compute_half
+ *   use_single      1: fp32 arithmetic on device (energy/virial sums in fp64); 0 (double) is not implemented yet
+ * On failure *out is NULL and ani_last_error(NULL) holds the message.
+ */
+int ani_create(const char* model_file, int local_rank, int use_num_models, int use_cuaev, int use_fullnbr,
+               int use_single, ani_handle** out);
+
+void ani_destroy(ani_handle* h);
+
+/* message of the last failure on this handle (or, with h == NULL, of the last failed ani_create) */
+const char* ani_last_error(const ani_handle* h);
+
+/* model.attr("num_models") / model.attr("use_num_models") (src/ani_csrc/ani.cpp:66,90) and model constants */
+int ani_num_models(const ani_handle* h);
+int ani_use_num_models(const ani_handle* h);
+int ani_num_species(const ani_handle* h);
+int ani_aev_length(const ani_handle* h);
+double ani_cutoff_radial(const ani_handle* h);
+double ani_cutoff_angular(const ani_handle* h);
+
+/*
+ * Replaces ANI::compute, full-neighbour-list overload (src/ani_csrc/ani.h:54-67, src/ani_csrc/ani.cpp:183-265).
+ *   species[ntotal]        0-based species (LAMMPS type-1, src/pair_ani.cpp:110); read only when ago == 0
+ *   coordinates[ntotal*3]  every call
+ *   ilist_unique[nlocal], numneigh[nlocal], jlist[npairs]
+ *                          the LAMMPS full list flattened in ilist order, neighbour indices already masked with
+ *                          NEIGHMASK (src/pair_ani.cpp:129-150); read only when ago == 0 and cached on the device
+ *                          otherwise (src/ani_csrc/ani.cpp:213-229).  numneigh[ii] belongs to centre ilist_unique[ii].
+ *   ago                    neighbor->ago: 0 = the list was rebuilt this step
+ *   eflag_atom, vflag      whether out_atomic_energies / out_virial are wanted
+ *   out_energy             total energy of the nlocal centres, self energies included
+ *   out_force[ntotal*3]    overwritten with -dE/dx for local AND ghost atoms (the caller reverse-communicates ghosts)
+ *   out_atomic_energies[nlocal]  per-centre energies in ilist order, or NULL
+ *   out_virial[9]          row-major 3x3, -sym(sum dE/d(diff) x diff) (models/lammps_ani.py:199-200,215), or NULL
+ */
+int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates,
+                     int64_t npairs, const int* ilist_unique, const int* jlist, const int* numneigh, int ago,
+                     int eflag_atom, int vflag, double* out_energy, double* out_force, double* out_atomic_energies,
+                     double* out_virial);
+
+/*
+ * Replaces ANI::compute, half-neighbour-list overload (src/ani_csrc/ani.h:39-51, src/ani_csrc/ani.cpp:100-180).
+ *   atom_index12[2*npairs_half]  [0:n] = i, [n:2n] = j (src/pair_ani.cpp:144-145); every atom < nlocal is a centre.
+ */
+int ani_compute_half(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates,
+                     int64_t npairs_half, const int64_t* atom_index12, int ago, int eflag_atom, int vflag,
+                     double* out_energy, double* out_force, double* out_atomic_energies, double* out_virial);
+
+/*
+ * Device-resident variant; replaces the Kokkos tensor overload (src/ani_csrc/ani.h:70-84,
+ * src/ani_csrc/ani.cpp:268-316, caller src/pair_ani_kokkos.cpp:143-191).  Every d_* pointer is device memory on the
+ * handle's device; nothing is copied to the host and nothing synchronises.
+ *   d_species[ntotal]   int32, read when ago == 0
+ *   d_x[ntotal*3]       double positions (LAMMPS atomKK->k_x layout)
+ *   d_ilist, d_numneigh, d_jlist   as above, int32, read when ago == 0 (cached / re-bucketed on the device)
+ *   d_f[ntotal*3]       double; forces are ADDED in place (src/pair_ani_kokkos.cpp:190-191)
+ *   d_ev[10]            double; overwritten with {energy, virial[9]} (virial zero unless vflag)
+ *   d_eatom[nlocal]     double per-centre energies (overwritten) or NULL
+ *   stream              hipStream_t to enqueue on (NULL = the handle's own stream)
+ */
+int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_species, const double* d_x,
+                            int64_t npairs, const int* d_ilist, const int* d_jlist, const int* d_numneigh, int ago,
+                            int eflag_atom, int vflag, double* d_f, double* d_ev, double* d_eatom, void* stream);
+
+/* last-step diagnostics for tests / roofline accounting (device pointers valid until the next compute or destroy) */
+typedef struct {
+  int nlocal, ntotal, nrows;       /* nrows: species-bucketed AEV rows incl. padding */
+  int64_t npairs;                  /* list pairs cached on the device */
+  const float* d_aev;              /* [nrows][aev_length] */
+  const float* d_gaev;             /* [nrows][aev_length]  dE/dAEV (Hartree) */
+  const int* d_row_of_centre;      /* [nlocal] row of centre ii */
+  int species_count[16];           /* centres per species */
+} ani_debug_view;
+int ani_debug_get(ani_handle* h, ani_debug_view* out);
+
+/* kernel timing hooks for bench.py: brackets the AEV / MLP phases of the NEXT computes with hipEvents on the
+ * compute stream; ani_phase_times returns accumulated milliseconds {aev_fwd, mlp, aev_bwd, other} and call count. */
+int ani_phase_timing(ani_handle* h, int enable);
+int ani_phase_times(ani_handle* h, double* ms4, int* ncalls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANI_HIP_H */

@@ -1,0 +1,151 @@
+"""ctypes binding of the C ABI in include/ani_hip.h (libani_hip.so).
+
+Mirrors the reference's ``class ANI`` (src/ani_csrc/ani.h:11-85): construct with the pair_style arguments, call
+``compute`` each step with ``ago`` telling whether the neighbour list was rebuilt.  There is no CPU fallback:
+if the library is missing or no GPU is visible this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_CSRC, "libani_hip.so")
+HARTREE2KCALMOL = 627.5094738898777
+
+EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani_use_num_models", "ani_num_species",
+           "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
+           "ani_compute_full_device", "ani_debug_get", "ani_phase_timing", "ani_phase_times"]
+
+
+class AniError(RuntimeError):
+    pass
+
+
+class DebugView(C.Structure):
+    _fields_ = [("nlocal", C.c_int), ("ntotal", C.c_int), ("nrows", C.c_int), ("npairs", C.c_int64),
+                ("d_aev", C.c_void_p), ("d_gaev", C.c_void_p), ("d_row_of_centre", C.c_void_p),
+                ("species_count", C.c_int * 16)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libani_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AniError(f"{LIB_PATH} is missing: build it (python -c 'import __graft_entry__ as g; g.build()'); "
+                           "there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        L.ani_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.ani_destroy.argtypes = [C.c_void_p]
+        L.ani_last_error.restype = C.c_char_p
+        L.ani_last_error.argtypes = [C.c_void_p]
+        for n in ("ani_num_models", "ani_use_num_models", "ani_num_species", "ani_aev_length"):
+            getattr(L, n).argtypes = [C.c_void_p]
+        for n in ("ani_cutoff_radial", "ani_cutoff_angular"):
+            getattr(L, n).argtypes = [C.c_void_p]
+            getattr(L, n).restype = C.c_double
+        L.ani_compute_full.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+        L.ani_compute_half.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+        L.ani_compute_full_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ani_debug_get.argtypes = [C.c_void_p, C.POINTER(DebugView)]
+        L.ani_phase_timing.argtypes = [C.c_void_p, C.c_int]
+        L.ani_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+class ANI:
+    """``ANI(model_file, local_rank, use_num_models, use_cuaev, use_fullnbr, use_single)`` — src/ani_csrc/ani.h:31-36."""
+
+    def __init__(self, model_file: str, local_rank: int = 0, use_num_models: int = -1, use_cuaev: bool = True,
+                 use_fullnbr: bool = True, use_single: bool = True):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        rc = self._lib.ani_create(model_file.encode(), local_rank, use_num_models, int(use_cuaev), int(use_fullnbr),
+                                  int(use_single), C.byref(self._h))
+        if rc != 0:
+            raise AniError(f"ani_create failed ({rc}): {self._lib.ani_last_error(None).decode()}")
+        self.use_cuaev, self.use_fullnbr, self.use_single = use_cuaev, use_fullnbr, use_single
+        self.num_models = self._lib.ani_num_models(self._h)
+        self.use_num_models = self._lib.ani_use_num_models(self._h)
+        self.aev_length = self._lib.ani_aev_length(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ani_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AniError(f"libani_hip error {rc}: {self._lib.ani_last_error(self._h).decode()}")
+
+    def compute(self, inp, ago: int = 0, eflag_atom: bool = True, vflag: bool = True):
+        """Host-pointer entry points with a harness.RankInput (full or half list).  Returns a dict like the oracle's."""
+        nt, nl = inp.ntotal, inp.nlocal
+        species = np.ascontiguousarray(inp.species, dtype=np.int64)
+        x = np.ascontiguousarray(inp.x, dtype=np.float64)
+        e = np.zeros(1)
+        f = np.full((nt, 3), np.nan)
+        ea = np.zeros(nl)
+        vir = np.zeros(9)
+        if inp.half:
+            a12 = np.ascontiguousarray(inp.atom_index12(), dtype=np.int64)
+            rc = self._lib.ani_compute_half(self._h, nt, nl, species.ctypes.data, x.ctypes.data, inp.npairs,
+                                            a12.ctypes.data, ago, int(eflag_atom), int(vflag), e.ctypes.data,
+                                            f.ctypes.data, ea.ctypes.data, vir.ctypes.data)
+        else:
+            il = np.ascontiguousarray(inp.ilist, dtype=np.int32)
+            nn = np.ascontiguousarray(inp.numneigh, dtype=np.int32)
+            jl = np.ascontiguousarray(inp.jlist, dtype=np.int32)
+            rc = self._lib.ani_compute_full(self._h, nt, nl, species.ctypes.data, x.ctypes.data, inp.npairs,
+                                            il.ctypes.data, jl.ctypes.data, nn.ctypes.data, ago, int(eflag_atom),
+                                            int(vflag), e.ctypes.data, f.ctypes.data, ea.ctypes.data, vir.ctypes.data)
+        self._check(rc)
+        return dict(energy=float(e[0]), force=f, eatom=ea, virial=vir.reshape(3, 3))
+
+    def compute_device(self, ntotal, nlocal, d_species, d_x, npairs, d_ilist, d_jlist, d_numneigh, ago, d_f, d_ev,
+                       d_eatom=None, eflag_atom=False, vflag=False, stream=None):
+        """Device-resident step; arguments are raw device addresses (e.g. torch tensor .data_ptr())."""
+        rc = self._lib.ani_compute_full_device(self._h, ntotal, nlocal, d_species, d_x, npairs, d_ilist, d_jlist,
+                                               d_numneigh, ago, int(eflag_atom), int(vflag), d_f, d_ev, d_eatom, stream)
+        self._check(rc)
+
+    def debug_view(self) -> DebugView:
+        v = DebugView()
+        self._check(self._lib.ani_debug_get(self._h, C.byref(v)))
+        return v
+
+    def phase_timing(self, enable: bool):
+        self._check(self._lib.ani_phase_timing(self._h, int(enable)))
+
+    def phase_times(self):
+        ms = (C.c_double * 4)()
+        n = C.c_int()
+        self._check(self._lib.ani_phase_times(self._h, ms, C.byref(n)))
+        return dict(aev_fwd=ms[0], mlp=ms[1], aev_bwd=ms[2], other=ms[3], calls=n.value)

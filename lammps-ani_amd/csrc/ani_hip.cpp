@@ -1,0 +1,556 @@
+// ani_hip.cpp — C ABI of libani_hip.so (include/ani_hip.h): model upload, device buffer management and the
+// per-step pipeline.  Replaces class ANI of the reference (src/ani_csrc/ani.cpp) without libtorch.
+//
+// Per step (all on one HIP stream, no per-step allocation once buffers have grown):
+//   [ago==0 only]  upload / copy the neighbour list, scan numneigh, bucket the centres by species (rows padded to
+//                  128 per species so that every GEMM tile is species-pure)            (ani.cpp:213-229)
+//   pack           double positions -> float4 {x,y,z,species}                          (ani.cpp:206-209)
+//   AEV forward    -> aev[nrows][aev_stride], rows in species-bucket order             (lammps_ani.py:174)
+//   MLP            forward + input-gradient backward on fp32 MFMA -> e_rows, gaev      (lammps_ani.py:182-184,197)
+//   AEV backward   gaev -> forces on local+ghost atoms, virial                         (lammps_ani.py:195-216)
+//   finish         fp64 energy sum + self energies, kcal/mol conversion                (ani.cpp:246-262)
+#include "../../include/ani_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ani_kernels.h"
+#include "ani_model.h"
+
+using namespace ani;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  // grow-only, 1.5x policy like the reference's jlist (src/pair_ani.cpp:119-127); contents are NOT preserved
+  hipError_t reserve(size_t n, bool zero = false) {
+    if (n <= cap && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    size_t want = std::max<size_t>(n + n / 2, 64);
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e != hipSuccess) { cap = 0; return e; }
+    cap = want;
+    if (zero) e = hipMemset(p, 0, want * sizeof(T));
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct SpeciesNet {
+  // device weights; layouts described in compute_mlp()
+  std::vector<float*> W;    // [L-1]   W[k]: [M][d[k+1]][kpad(k)]        forward, k = 0..L-2
+  std::vector<float*> b;    // [L-1]   b[k]: [M][d[k+1]]
+  std::vector<float*> WT;   // [L-1]   WT[k], k = 1..L-2: [M][d[k]][w(k+1)] ; WT[0]: [aev_len][M*w(1)]
+  float* w_out = nullptr;   // [M][w(L-1)]
+  float* b_out = nullptr;   // [M]
+  std::vector<int> w;       // w[k] = round_up(d[k],4), k = 0..L-1 (w[0] = aev_stride)
+};
+
+}  // namespace
+
+struct ani_handle {
+  HostModel model;
+  AevParams ap;
+  int device = 0;
+  bool use_cuaev = true, use_fullnbr = true, use_single = true;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<SpeciesNet> nets;
+
+  // list epoch state (valid while ago > 0)
+  bool have_list = false;
+  int nlocal = 0, ntotal = 0, nrows = 0;
+  long long npairs = 0;
+  int count[kMaxSpecies] = {0}, row_start[kMaxSpecies] = {0};
+
+  DevBuf<int> species, ilist, numneigh, jlist, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
+  DevBuf<float4> xyzs;
+  DevBuf<double> x64, f64, ev, eatom, partial, virial_acc;
+  DevBuf<float> aev, gaev, act, e_rows, fbuf;
+  std::vector<std::vector<float*>> Hbuf, Gbuf;  // [S][k] pointers into act
+  // host staging for the host-pointer entry points
+  std::vector<int> h_species32;
+  std::vector<int> h_half_num, h_half_j;
+
+  // phase timing
+  bool timing = false;
+  hipEvent_t evt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double phase_ms[4] = {0, 0, 0, 0};
+  int phase_calls = 0;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                              \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess) {                                                                           \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                   \
+      return ANI_ERR_DEVICE;                                                                          \
+    }                                                                                                 \
+  } while (0)
+
+int upload(ani_handle* h, float** dst, const std::vector<float>& src) {
+  HIP_TRY(h, hipMalloc((void**)dst, std::max<size_t>(src.size(), 1) * sizeof(float)));
+  HIP_TRY(h, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+  return ANI_OK;
+}
+
+int upload_model(ani_handle* h) {
+  const HostModel& m = h->model;
+  const int L = m.L, M = m.M;
+  const int aev_stride = round_up(m.aev_len, 4);
+  h->nets.resize(m.S);
+  for (int s = 0; s < m.S; s++) {
+    SpeciesNet& n = h->nets[s];
+    const std::vector<int>& d = m.dims[s];
+    n.w.resize(L);
+    n.w[0] = aev_stride;
+    for (int k = 1; k < L; k++) n.w[k] = round_up(d[k], 4);
+    if (d[L - 1] > 256) { h->err = "last hidden layer wider than 256 is not supported"; return ANI_ERR_MODEL; }
+    n.W.assign(L - 1, nullptr); n.b.assign(L - 1, nullptr); n.WT.assign(L - 1, nullptr);
+    for (int k = 0; k < L - 1; k++) {
+      const int out = d[k + 1], in = d[k], kp = n.w[k];
+      std::vector<float> W((size_t)M * out * kp, 0.f), b((size_t)M * out);
+      for (int a = 0; a < M; a++) {
+        for (int o = 0; o < out; o++) {
+          memcpy(&W[((size_t)a * out + o) * kp], &m.W[a][s][k][(size_t)o * in], sizeof(float) * in);
+          b[(size_t)a * out + o] = m.b[a][s][k][o];
+        }
+      }
+      int rc = upload(h, &n.W[k], W); if (rc) return rc;
+      rc = upload(h, &n.b[k], b); if (rc) return rc;
+      // transposed copies for the backward products
+      if (k == 0) {
+        const int w1 = n.w[1];
+        std::vector<float> T((size_t)m.aev_len * M * w1, 0.f);   // [aev_len][M*w1]
+        for (int a = 0; a < M; a++)
+          for (int o = 0; o < out; o++)
+            for (int i = 0; i < in; i++) T[(size_t)i * M * w1 + (size_t)a * w1 + o] = m.W[a][s][0][(size_t)o * in + i];
+        rc = upload(h, &n.WT[0], T); if (rc) return rc;
+      } else {
+        const int wk1 = n.w[k + 1 < L ? k + 1 : k];  // K of the backward product through layer k = padded d[k+1]
+        std::vector<float> T((size_t)M * in * wk1, 0.f);         // [M][d[k]][w(k+1)]
+        for (int a = 0; a < M; a++)
+          for (int o = 0; o < out; o++)
+            for (int i = 0; i < in; i++) T[((size_t)a * in + i) * wk1 + o] = m.W[a][s][k][(size_t)o * in + i];
+        rc = upload(h, &n.WT[k], T); if (rc) return rc;
+      }
+    }
+    {  // output layer
+      const int in = d[L - 1], kp = n.w[L - 1];
+      std::vector<float> w((size_t)M * kp, 0.f), b(M);
+      for (int a = 0; a < M; a++) {
+        memcpy(&w[(size_t)a * kp], m.W[a][s][L - 1].data(), sizeof(float) * in);
+        b[a] = m.b[a][s][L - 1][0];
+      }
+      int rc = upload(h, &n.w_out, w); if (rc) return rc;
+      rc = upload(h, &n.b_out, b); if (rc) return rc;
+    }
+  }
+  AevParams& p = h->ap;
+  memset(&p, 0, sizeof(p));
+  p.S = m.S; p.nR = m.nR; p.nA = m.nA; p.nZ = m.nZ; p.nAZ = m.nA * m.nZ;
+  p.radial_len = m.radial_len; p.aev_len = m.aev_len; p.aev_stride = aev_stride;
+  p.compat = h->use_cuaev ? 0 : 1;
+  p.Rcr = (float)m.Rcr; p.Rca = (float)m.Rca; p.EtaR = (float)m.EtaR; p.EtaA = (float)m.EtaA; p.Zeta = (float)m.Zeta;
+  p.pi_over_Rcr = (float)(M_PI / m.Rcr); p.pi_over_Rca = (float)(M_PI / m.Rca);
+  for (int k = 0; k < m.nR; k++) p.ShfR[k] = (float)m.ShfR[k];
+  for (int k = 0; k < m.nA; k++) p.ShfA[k] = (float)m.ShfA[k];
+  for (int k = 0; k < m.nZ; k++) { p.cosZ[k] = (float)cos(m.ShfZ[k]); p.sinZ[k] = (float)sin(m.ShfZ[k]); }
+  if (aev_stride > 1024) { h->err = "AEV longer than 1024 is not supported"; return ANI_ERR_MODEL; }
+  return ANI_OK;
+}
+
+// (re)build everything that depends on the neighbour list: offsets, species buckets, activation arena.
+// d_species/d_ilist/d_numneigh/d_jlist already hold this epoch's list in the handle's own buffers.
+int rebuild(ani_handle* h, hipStream_t st) {
+  const HostModel& m = h->model;
+  const int nlocal = h->nlocal;
+  const int nrows_cap = round_up(nlocal, kRowTile) + m.S * kRowTile;
+  HIP_TRY(h, h->nbr_off.reserve((size_t)nlocal + 1));
+  HIP_TRY(h, h->row_of_centre.reserve((size_t)2 * nlocal + 2));
+  HIP_TRY(h, h->centre_of_row.reserve(nrows_cap));
+  HIP_TRY(h, h->bucket_info.reserve(2 * kMaxSpecies + 2));
+  PrepOut o{h->nbr_off.p, h->row_of_centre.p, h->centre_of_row.p, h->bucket_info.p};
+  launch_prepare(h->species.p, h->ilist.p, h->numneigh.p, nlocal, h->ntotal, m.S, nrows_cap, o, st);
+  int info[2 * kMaxSpecies + 2];
+  HIP_TRY(h, hipMemcpyAsync(info, h->bucket_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));
+  if (info[2 * kMaxSpecies + 1]) { h->err = "an atom has a species outside the model's species list (or ilist holds an index outside [0, ntotal))"; return ANI_ERR_ARG; }
+  for (int s = 0; s < m.S; s++) { h->count[s] = info[s]; h->row_start[s] = info[kMaxSpecies + s]; }
+  h->nrows = info[2 * kMaxSpecies];
+
+  const size_t stride = h->ap.aev_stride;
+  HIP_TRY(h, h->aev.reserve((size_t)std::max(h->nrows, 1) * stride));
+  HIP_TRY(h, h->gaev.reserve((size_t)std::max(h->nrows, 1) * stride));
+  HIP_TRY(h, hipMemsetAsync(h->aev.p, 0, (size_t)h->nrows * stride * sizeof(float), st));  // padding rows stay zero
+  HIP_TRY(h, h->e_rows.reserve((size_t)m.M * std::max(h->nrows, 1)));
+
+  // activation arena: per species, H_k (k = 1..L-2, reused in place as G_k) and G_{L-1}
+  size_t need = 0;
+  for (int s = 0; s < m.S; s++) {
+    const size_t rows = round_up(h->count[s], kRowTile);
+    for (int k = 1; k < m.L; k++) need += rows * (size_t)m.M * h->nets[s].w[k];
+  }
+  HIP_TRY(h, h->act.reserve(std::max<size_t>(need, 1)));
+  HIP_TRY(h, hipMemsetAsync(h->act.p, 0, need * sizeof(float), st));  // zero K-padding columns
+  h->Hbuf.assign(m.S, std::vector<float*>(m.L, nullptr));
+  size_t off = 0;
+  for (int s = 0; s < m.S; s++) {
+    const size_t rows = round_up(h->count[s], kRowTile);
+    for (int k = 1; k < m.L; k++) {
+      h->Hbuf[s][k] = h->act.p + off;
+      off += rows * (size_t)m.M * h->nets[s].w[k];
+    }
+  }
+  return ANI_OK;
+}
+
+// The MLP ensemble for every species bucket.  Buffers of species s are local to the bucket (row 0 = row_start[s]).
+//   W[k]  : [M][d[k+1]][w[k]]   Bt of forward layer k (K = w[k], zero padded)
+//   WT[k] : [M][d[k]][w[k+1]]   Bt of the backward product through layer k (k >= 1);  WT[0]: [aev_len][M*w[1]]
+//   H_k   : [rows][M*w[k]]      activations after layer k-1 (member a at column a*w[k]); overwritten by G_k = dE/dz_k
+void compute_mlp(ani_handle* h, hipStream_t st) {
+  const HostModel& m = h->model;
+  const int L = m.L, M = m.M;
+  const float alpha = (float)m.alpha, inv_alpha = (float)(1.0 / m.alpha);
+  for (int s = 0; s < m.S; s++) {
+    if (h->count[s] == 0) continue;
+    const SpeciesNet& n = h->nets[s];
+    const std::vector<int>& d = m.dims[s];
+    const int rows = round_up(h->count[s], kRowTile);
+    const int r0 = h->row_start[s];
+    const float* aev = h->aev.p + (size_t)r0 * h->ap.aev_stride;
+    float* gaev = h->gaev.p + (size_t)r0 * h->ap.aev_stride;
+    const int* cor = h->centre_of_row.p + r0;
+    // forward
+    for (int k = 0; k <= L - 2; k++) {
+      GemmArgs g{};
+      g.rows = rows; g.row0 = 0; g.batch = M; g.alpha = alpha; g.inv_alpha = inv_alpha; g.scale = 1.f / (float)M;
+      g.centre_of_row = cor;
+      if (k == 0) { g.A = aev; g.lda = h->ap.aev_stride; g.sA = 0; }
+      else { g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k]; }
+      g.K = n.w[k];
+      g.Bt = n.W[k]; g.ldb = n.w[k]; g.sB = (long long)d[k + 1] * n.w[k];
+      g.N = d[k + 1];
+      g.bias = n.b[k]; g.sBias = d[k + 1];
+      g.C = h->Hbuf[s][k + 1]; g.ldc = M * n.w[k + 1]; g.sC = n.w[k + 1];
+      if (k == L - 2) {
+        g.aux = n.w_out; g.sAux = n.w[L - 1];
+        g.bias_last = n.b_out;
+        g.e_out = h->e_rows.p + r0; g.sE = h->nrows;
+        launch_gemm(g, EPI_LAST, st);
+      } else {
+        launch_gemm(g, EPI_CELU, st);
+      }
+    }
+    // backward: G_{k-1} = (G_k W[k-1]) * celu'(z_{k-1}), in place over H_{k-1}
+    for (int k = L - 1; k >= 2; k--) {
+      GemmArgs g{};
+      g.rows = rows; g.row0 = 0; g.batch = M; g.alpha = alpha; g.inv_alpha = inv_alpha;
+      g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k]; g.K = n.w[k];
+      g.Bt = n.WT[k - 1]; g.ldb = n.w[k]; g.sB = (long long)d[k - 1] * n.w[k];
+      g.N = d[k - 1];
+      g.aux = h->Hbuf[s][k - 1]; g.ldaux = M * n.w[k - 1]; g.sAux = n.w[k - 1];
+      g.C = h->Hbuf[s][k - 1]; g.ldc = M * n.w[k - 1]; g.sC = n.w[k - 1];
+      launch_gemm(g, EPI_BWD, st);
+    }
+    {  // dE/dAEV = sum over members of G_1 W[0]  (members concatenated along K)
+      GemmArgs g{};
+      g.rows = rows; g.row0 = 0; g.batch = 1;
+      g.A = h->Hbuf[s][1]; g.lda = M * n.w[1]; g.K = M * n.w[1];
+      g.Bt = n.WT[0]; g.ldb = M * n.w[1];
+      g.N = m.aev_len;
+      g.C = gaev; g.ldc = h->ap.aev_stride;
+      launch_gemm(g, EPI_PLAIN, st);
+    }
+  }
+}
+
+// the per-step pipeline on device-resident inputs; the list of this epoch is already in the handle's buffers
+int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double* d_f, int f_accumulate, double* d_ev,
+             double* d_eatom, hipStream_t st) {
+  const HostModel& m = h->model;
+  HIP_TRY(h, h->xyzs.reserve(h->ntotal));
+  HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 3));
+  HIP_TRY(h, h->partial.reserve(256));
+  HIP_TRY(h, h->virial_acc.reserve(9));
+  HIP_TRY(h, h->err_flag.reserve(1, true));
+  if (h->timing) for (int i = 0; i < 5; i++) if (!h->evt[i]) HIP_TRY(h, hipEventCreate(&h->evt[i]));
+
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[0], st));
+  launch_pack(d_x, h->species.p, h->ntotal, h->xyzs.p, st);
+  HIP_TRY(h, hipMemsetAsync(h->fbuf.p, 0, sizeof(float) * 3 * (size_t)h->ntotal, st));
+  HIP_TRY(h, hipMemsetAsync(h->virial_acc.p, 0, sizeof(double) * 9, st));
+
+  AevArgs a{};
+  a.xyzs = h->xyzs.p; a.ilist = h->ilist.p; a.numneigh = h->numneigh.p; a.nbr_off = h->nbr_off.p; a.jlist = h->jlist.p;
+  a.centre_of_row = h->centre_of_row.p; a.nrows = h->nrows; a.aev = h->aev.p; a.gaev = h->gaev.p; a.fbuf = h->fbuf.p;
+  a.virial = vflag ? h->virial_acc.p : nullptr;
+  a.err_flag = h->err_flag.p;
+  launch_aev_forward(h->ap, a, st);
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[1], st));
+  compute_mlp(h, st);
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[2], st));
+  launch_aev_backward(h->ap, a, st);
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[3], st));
+
+  FinishArgs fa{};
+  fa.e_rows = h->e_rows.p; fa.M = m.M; fa.nrows = h->nrows; fa.nrows_ld = h->nrows;
+  fa.centre_of_row = h->centre_of_row.p; fa.ilist = h->ilist.p; fa.species = h->species.p;
+  for (int s = 0; s < m.S; s++) fa.sae[s] = m.sae[s];
+  fa.fbuf = h->fbuf.p; fa.ntotal = h->ntotal;
+  fa.virial_acc = vflag ? h->virial_acc.p : nullptr;
+  fa.f_out = d_f; fa.f_accumulate = f_accumulate; fa.ev_out = d_ev;
+  fa.eatom_out = eflag_atom ? d_eatom : nullptr;
+  fa.partial = h->partial.p;
+  fa.err_flag = h->err_flag.p;
+  launch_finish(fa, st);
+  if (h->timing) {
+    HIP_TRY(h, hipEventRecord(h->evt[4], st));
+    HIP_TRY(h, hipEventSynchronize(h->evt[4]));
+    float t;
+    for (int i = 0; i < 4; i++) { HIP_TRY(h, hipEventElapsedTime(&t, h->evt[i], h->evt[i + 1])); h->phase_ms[i] += t; }
+    h->phase_calls++;
+  }
+  HIP_TRY(h, hipGetLastError());
+  return ANI_OK;
+}
+
+int check_args(ani_handle* h, int ntotal, int nlocal, long long npairs, int ago) {
+  if (!h) return ANI_ERR_ARG;
+  if (ntotal < 0 || nlocal < 0 || nlocal > ntotal || npairs < 0) { h->err = "inconsistent ntotal/nlocal/npairs"; return ANI_ERR_ARG; }
+  if (npairs >= (1LL << 31)) { h->err = "more than 2^31 neighbour pairs per rank is not supported"; return ANI_ERR_ARG; }
+  if (ago != 0 && (!h->have_list || ntotal != h->ntotal || nlocal != h->nlocal)) {
+    h->err = "ago != 0 but no neighbour list of matching size is cached (the first call, and every call after a rebuild, must pass ago = 0)";
+    return ANI_ERR_ARG;
+  }
+  return ANI_OK;
+}
+
+int finish_host(ani_handle* h, int ntotal, int nlocal, int eflag_atom, int vflag, double* out_energy, double* out_force,
+                double* out_atomic_energies, double* out_virial) {
+  hipStream_t st = h->stream;
+  double ev[10];
+  int flag = 0;
+  HIP_TRY(h, hipMemcpyAsync(ev, h->ev.p, sizeof(ev), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipMemcpyAsync(&flag, h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (out_force) HIP_TRY(h, hipMemcpyAsync(out_force, h->f64.p, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyDeviceToHost, st));
+  if (eflag_atom && out_atomic_energies)
+    HIP_TRY(h, hipMemcpyAsync(out_atomic_energies, h->eatom.p, sizeof(double) * (size_t)nlocal, hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));
+  if (flag) {
+    HIP_TRY(h, hipMemsetAsync(h->err_flag.p, 0, sizeof(int), st));
+    h->err = "an atom has more neighbours inside the radial/angular cutoff than the kernels' LDS capacity (" +
+             std::to_string(kMaxRad) + "/" + std::to_string(kMaxAng) + ")";
+    return ANI_ERR_CAPACITY;
+  }
+  if (out_energy) *out_energy = ev[0];
+  if (vflag && out_virial) memcpy(out_virial, ev + 1, sizeof(double) * 9);
+  return ANI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ani_create(const char* model_file, int local_rank, int use_num_models, int use_cuaev, int use_fullnbr, int use_single,
+               ani_handle** out) {
+  if (out) *out = nullptr;
+  if (!model_file || !out) { g_create_error = "null argument"; return ANI_ERR_ARG; }
+  if (local_rank < 0) {
+    g_create_error = "device 'cpu' (local_rank = -1) is not available: libani_hip is the HIP/gfx950 path only and has no host fallback";
+    return ANI_ERR_ARG;
+  }
+  if (!use_single) {
+    g_create_error = "precision 'double' is not implemented in libani_hip yet (use 'single')";
+    return ANI_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device visible"; return ANI_ERR_DEVICE; }
+  ani_handle* h = new ani_handle;
+  h->device = local_rank % ndev;  // src/pair_ani.cpp:269-272
+  h->use_cuaev = use_cuaev != 0; h->use_fullnbr = use_fullnbr != 0; h->use_single = true;
+  std::string e = load_model(model_file, use_num_models, h->model);
+  if (!e.empty()) { g_create_error = e; delete h; return ANI_ERR_MODEL; }
+  if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_create_error = "cannot initialise HIP device " + std::to_string(h->device);
+    delete h;
+    return ANI_ERR_DEVICE;
+  }
+  int rc = upload_model(h);
+  if (rc != ANI_OK) { g_create_error = h->err; ani_destroy(h); return rc; }
+  // banner, same fields as src/ani_csrc/ani.cpp:88-92
+  printf("Successfully loaded the model \nfile: '%s' \ndevice: hip:%d \ndtype: float (FP32) \nnbrlist: %s \nani_aev: %s \nuse_num_models: %d/%d\n\n",
+         model_file, h->device, h->use_fullnbr ? "full" : "half", h->use_cuaev ? "cuaev" : "pyaev", h->model.M, h->model.M_file);
+  fflush(stdout);
+  *out = h;
+  return ANI_OK;
+}
+
+void ani_destroy(ani_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& n : h->nets) {
+    for (float* p : n.W) if (p) (void)hipFree(p);
+    for (float* p : n.b) if (p) (void)hipFree(p);
+    for (float* p : n.WT) if (p) (void)hipFree(p);
+    if (n.w_out) (void)hipFree(n.w_out);
+    if (n.b_out) (void)hipFree(n.b_out);
+  }
+  h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->nbr_off.release();
+  h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
+  h->xyzs.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release();
+  h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->e_rows.release(); h->fbuf.release();
+  for (auto& e : h->evt) if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* ani_last_error(const ani_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+int ani_num_models(const ani_handle* h) { return h ? h->model.M_file : 0; }
+int ani_use_num_models(const ani_handle* h) { return h ? h->model.M : 0; }
+int ani_num_species(const ani_handle* h) { return h ? h->model.S : 0; }
+int ani_aev_length(const ani_handle* h) { return h ? h->model.aev_len : 0; }
+double ani_cutoff_radial(const ani_handle* h) { return h ? h->model.Rcr : 0; }
+double ani_cutoff_angular(const ani_handle* h) { return h ? h->model.Rca : 0; }
+
+int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_species, const double* d_x, int64_t npairs,
+                            const int* d_ilist, const int* d_jlist, const int* d_numneigh, int ago, int eflag_atom, int vflag,
+                            double* d_f, double* d_ev, double* d_eatom, void* stream) {
+  int rc = check_args(h, ntotal, nlocal, npairs, ago);
+  if (rc) return rc;
+  if (!d_x || !d_ev) { h->err = "null device pointer"; return ANI_ERR_ARG; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  if (ago == 0) {
+    if (!d_species || !d_ilist || !d_jlist || !d_numneigh) { h->err = "null list pointer with ago == 0"; return ANI_ERR_ARG; }
+    h->ntotal = ntotal; h->nlocal = nlocal; h->npairs = npairs;
+    HIP_TRY(h, h->species.reserve(ntotal));
+    HIP_TRY(h, h->ilist.reserve(nlocal));
+    HIP_TRY(h, h->numneigh.reserve(nlocal));
+    HIP_TRY(h, h->jlist.reserve(npairs));
+    HIP_TRY(h, hipMemcpyAsync(h->species.p, d_species, sizeof(int) * (size_t)ntotal, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->ilist.p, d_ilist, sizeof(int) * (size_t)nlocal, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, d_numneigh, sizeof(int) * (size_t)nlocal, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->jlist.p, d_jlist, sizeof(int) * (size_t)npairs, hipMemcpyDeviceToDevice, st));
+    h->have_list = false;
+    rc = rebuild(h, st);
+    if (rc) return rc;
+    h->have_list = true;
+  }
+  return run_step(h, d_x, eflag_atom, vflag, d_f, /*accumulate=*/1, d_ev, d_eatom, st);
+}
+
+int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates, int64_t npairs,
+                     const int* ilist_unique, const int* jlist, const int* numneigh, int ago, int eflag_atom, int vflag,
+                     double* out_energy, double* out_force, double* out_atomic_energies, double* out_virial) {
+  int rc = check_args(h, ntotal, nlocal, npairs, ago);
+  if (rc) return rc;
+  if (!coordinates || !out_force || !out_energy) { h->err = "null pointer argument"; return ANI_ERR_ARG; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  if (ago == 0) {
+    if (!species || !ilist_unique || !numneigh || (npairs > 0 && !jlist)) { h->err = "null list pointer with ago == 0"; return ANI_ERR_ARG; }
+    h->ntotal = ntotal; h->nlocal = nlocal; h->npairs = npairs;
+    h->h_species32.resize(ntotal);
+    for (int i = 0; i < ntotal; i++) h->h_species32[i] = (int)species[i];
+    HIP_TRY(h, h->species.reserve(ntotal));
+    HIP_TRY(h, h->ilist.reserve(nlocal));
+    HIP_TRY(h, h->numneigh.reserve(nlocal));
+    HIP_TRY(h, h->jlist.reserve(npairs));
+    HIP_TRY(h, hipMemcpyAsync(h->species.p, h->h_species32.data(), sizeof(int) * (size_t)ntotal, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->ilist.p, ilist_unique, sizeof(int) * (size_t)nlocal, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, numneigh, sizeof(int) * (size_t)nlocal, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->jlist.p, jlist, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice, st));
+    h->have_list = false;
+    rc = rebuild(h, st);
+    if (rc) return rc;
+    h->have_list = true;
+  }
+  HIP_TRY(h, h->x64.reserve((size_t)ntotal * 3));
+  HIP_TRY(h, h->f64.reserve((size_t)ntotal * 3));
+  HIP_TRY(h, h->ev.reserve(10));
+  HIP_TRY(h, h->eatom.reserve(std::max(nlocal, 1)));
+  HIP_TRY(h, hipMemcpyAsync(h->x64.p, coordinates, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyHostToDevice, st));
+  rc = run_step(h, h->x64.p, eflag_atom, vflag, h->f64.p, /*accumulate=*/0, h->ev.p, h->eatom.p, st);
+  if (rc) return rc;
+  return finish_host(h, ntotal, nlocal, eflag_atom, vflag, out_energy, out_force, out_atomic_energies, out_virial);
+}
+
+int ani_compute_half(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates, int64_t npairs_half,
+                     const int64_t* atom_index12, int ago, int eflag_atom, int vflag, double* out_energy, double* out_force,
+                     double* out_atomic_energies, double* out_virial) {
+  if (!h) return ANI_ERR_ARG;
+  // A half pair feeds both of its local ends (src/ani_csrc/ani.cpp:100-180: every atom < nlocal is a centre), so the
+  // half list is expanded once per rebuild into the per-centre form the kernels consume.
+  if (ago == 0) {
+    if (!atom_index12 && npairs_half > 0) { h->err = "null atom_index12 with ago == 0"; return ANI_ERR_ARG; }
+    std::vector<int>& num = h->h_half_num;
+    std::vector<int>& jl = h->h_half_j;
+    num.assign(nlocal, 0);
+    for (int64_t p = 0; p < npairs_half; p++) {
+      const int64_t a = atom_index12[p], b = atom_index12[npairs_half + p];
+      if (a < 0 || a >= ntotal || b < 0 || b >= ntotal) { h->err = "atom_index12 entry out of range"; return ANI_ERR_ARG; }
+      if (a < nlocal) num[a]++;
+      if (b < nlocal) num[b]++;
+    }
+    std::vector<int64_t> off(nlocal + 1, 0);
+    for (int i = 0; i < nlocal; i++) off[i + 1] = off[i] + num[i];
+    jl.resize(off[nlocal]);
+    std::vector<int64_t> fill(off.begin(), off.end() - 1);
+    for (int64_t p = 0; p < npairs_half; p++) {
+      const int64_t a = atom_index12[p], b = atom_index12[npairs_half + p];
+      if (a < nlocal) jl[fill[a]++] = (int)b;
+      if (b < nlocal) jl[fill[b]++] = (int)a;
+    }
+    std::vector<int> il(nlocal);
+    for (int i = 0; i < nlocal; i++) il[i] = i;
+    return ani_compute_full(h, ntotal, nlocal, species, coordinates, (int64_t)jl.size(), il.data(), jl.data(), num.data(), 0,
+                            eflag_atom, vflag, out_energy, out_force, out_atomic_energies, out_virial);
+  }
+  return ani_compute_full(h, ntotal, nlocal, species, coordinates, h->npairs, nullptr, nullptr, nullptr, ago, eflag_atom, vflag,
+                          out_energy, out_force, out_atomic_energies, out_virial);
+}
+
+int ani_debug_get(ani_handle* h, ani_debug_view* out) {
+  if (!h || !out) return ANI_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  out->nlocal = h->nlocal; out->ntotal = h->ntotal; out->nrows = h->nrows; out->npairs = h->npairs;
+  out->d_aev = h->aev.p; out->d_gaev = h->gaev.p; out->d_row_of_centre = h->row_of_centre.p;
+  for (int s = 0; s < kMaxSpecies && s < 16; s++) out->species_count[s] = h->count[s];
+  return ANI_OK;
+}
+
+int ani_phase_timing(ani_handle* h, int enable) {
+  if (!h) return ANI_ERR_ARG;
+  h->timing = enable != 0;
+  for (double& v : h->phase_ms) v = 0;
+  h->phase_calls = 0;
+  return ANI_OK;
+}
+
+int ani_phase_times(ani_handle* h, double* ms4, int* ncalls) {
+  if (!h || !ms4 || !ncalls) return ANI_ERR_ARG;
+  for (int i = 0; i < 4; i++) ms4[i] = h->phase_ms[i];
+  *ncalls = h->phase_calls;
+  return ANI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// ani_kernels_misc.hip — the small kernels around the two hot passes: position packing, rebuild-time list
+// preparation (what src/ani_csrc/ani.cpp:213-229 and models/lammps_ani.py:156-166 do with torch ops every
+// rebuild / every step), and the final reductions / unit conversion (src/ani_csrc/ani.cpp:246-262).
+#include "ani_kernels.h"
+
+namespace ani {
+
+__global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int ntotal, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntotal) return;
+  // coordinates.to(dtype): src/ani_csrc/ani.cpp:206-207
+  out[i] = make_float4((float)x[3 * i], (float)x[3 * i + 1], (float)x[3 * i + 2], __int_as_float(species[i]));
+}
+
+void launch_pack(const double* d_x, const int* d_species, int ntotal, float4* xyzs, hipStream_t st) {
+  if (ntotal <= 0) return;
+  hipLaunchKernelGGL(pack_kernel, dim3((ntotal + 255) / 256), dim3(256), 0, st, d_x, d_species, ntotal, xyzs);
+}
+
+// ---- rebuild-time preparation ------------------------------------------------------------------------
+// block-wide exclusive scan of one int per thread (1024 threads = 16 waves); returns the block total
+__device__ __forceinline__ int block_exclusive_scan(int v, int& total, int* wave_sums) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  const int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; w++) {
+    const int s = wave_sums[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  total = tot;
+  return base + incl - v;
+}
+
+// block 0: exclusive scan of numneigh; blocks 1..S: stable rank of the centres of species s-1.
+// The species counts are needed before ranks can be turned into rows, hence two kernels.
+__global__ __launch_bounds__(1024) void prepare_count_kernel(const int* __restrict__ species, const int* __restrict__ ilist,
+                                                              const int* __restrict__ numneigh, int nlocal, int ntotal, int S,
+                                                              PrepOut o, int* __restrict__ rank_in_species) {
+  __shared__ int wave_sums[16];
+  int carry = 0;
+  if (blockIdx.x == 0) {
+    for (int base = 0; base < nlocal; base += blockDim.x) {
+      const int ii = base + threadIdx.x;
+      const int v = ii < nlocal ? numneigh[ii] : 0;
+      int total;
+      const int ex = block_exclusive_scan(v, total, wave_sums);
+      if (ii < nlocal) o.nbr_off[ii] = carry + ex;
+      carry += total;
+    }
+    if (threadIdx.x == 0) o.nbr_off[nlocal] = carry;
+  } else if ((int)blockIdx.x <= S) {
+    const int s = blockIdx.x - 1;
+    for (int base = 0; base < nlocal; base += blockDim.x) {
+      const int ii = base + threadIdx.x;
+      const int flag = (ii < nlocal && species[ilist[ii]] == s) ? 1 : 0;
+      int total;
+      const int ex = block_exclusive_scan(flag, total, wave_sums);
+      if (flag) rank_in_species[ii] = carry + ex;
+      carry += total;
+    }
+    if (threadIdx.x == 0) o.bucket_info[s] = carry;
+  } else {
+    // species outside [0,S): flag it (the reference would fail inside the network lookup)
+    int bad = 0;
+    // every atom, ghosts included: neighbour species index the AEV row
+    for (int i = threadIdx.x; i < ntotal; i += blockDim.x) {
+      const int sp = species[i];
+      if (sp < 0 || sp >= S) bad = 1;
+    }
+    for (int ii = threadIdx.x; ii < nlocal; ii += blockDim.x) {
+      const int i = ilist[ii];
+      if (i < 0 || i >= ntotal) bad = 1;
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0) o.bucket_info[2 * kMaxSpecies + 1] = 1;
+  }
+}
+
+__global__ void prepare_rows_kernel(const int* __restrict__ species, const int* __restrict__ ilist, int nlocal, int S,
+                                    int nrows_cap, PrepOut o, const int* __restrict__ rank_in_species) {
+  __shared__ int row_start[kMaxSpecies + 1];
+  if (threadIdx.x == 0) {
+    int r = 0;
+    for (int s = 0; s < S; s++) {
+      row_start[s] = r;
+      r += (o.bucket_info[s] + kRowTile - 1) / kRowTile * kRowTile;
+    }
+    row_start[S] = r;
+    if (blockIdx.x == 0) {
+      for (int s = 0; s < S; s++) o.bucket_info[kMaxSpecies + s] = row_start[s];
+      o.bucket_info[2 * kMaxSpecies] = r;
+    }
+  }
+  __syncthreads();
+  const int ii = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ii >= nlocal) return;
+  const int sp = species[ilist[ii]];
+  if (sp < 0 || sp >= S) { o.row_of_centre[ii] = -1; return; }
+  const int row = row_start[sp] + rank_in_species[ii];
+  o.row_of_centre[ii] = row;
+  if (row < nrows_cap) o.centre_of_row[row] = ii;
+}
+
+void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
+                    const PrepOut& o, hipStream_t st) {
+  // row_of_centre is sized 2*nlocal by the caller: the second half is the rank-in-species scratch
+  int* rank = o.row_of_centre + nlocal;
+  (void)hipMemsetAsync(o.centre_of_row, 0xff, sizeof(int) * (size_t)nrows_cap, st);
+  (void)hipMemsetAsync(o.bucket_info, 0, sizeof(int) * (2 * kMaxSpecies + 2), st);
+  hipLaunchKernelGGL(prepare_count_kernel, dim3(S + 2), dim3(1024), 0, st, d_species, d_ilist, d_numneigh, nlocal, ntotal, S, o, rank);
+  if (nlocal > 0)
+    hipLaunchKernelGGL(prepare_rows_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, st, d_species, d_ilist, nlocal, S,
+                       nrows_cap, o, rank);
+  else
+    hipLaunchKernelGGL(prepare_rows_kernel, dim3(1), dim3(256), 0, st, d_species, d_ilist, nlocal, S, nrows_cap, o, rank);
+}
+
+// ---- final reductions ------------------------------------------------------------------------------------
+constexpr int kFinishBlocks = 256;
+
+__global__ __launch_bounds__(256) void finish_energy_kernel(FinishArgs a) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < a.nrows; row += gridDim.x * blockDim.x) {
+    const int ii = a.centre_of_row[row];
+    if (ii < 0) continue;
+    float e = 0.f;
+    for (int m = 0; m < a.M; m++) e += a.e_rows[(long long)m * a.nrows_ld + row];
+    // energy_shifter (models/lammps_ani.py:230,250), self energy added in fp64
+    const double ea = (double)e + a.sae[a.species[a.ilist[ii]]];
+    if (a.eatom_out) a.eatom_out[ii] = ea * 627.5094738898777;
+    acc += ea;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void finish_final_kernel(FinishArgs a) {
+  __shared__ double red[256];
+  red[threadIdx.x] = threadIdx.x < kFinishBlocks ? a.partial[threadIdx.x] : 0.0;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.ev_out[0] = (a.err_flag && *a.err_flag) ? __longlong_as_double(0x7ff8000000000000LL) : red[0] * 627.5094738898777;
+  if (threadIdx.x < 9) {
+    const int k = threadIdx.x / 3, l = threadIdx.x % 3;
+    // (virial.t() + virial)/2 : models/lammps_ani.py:200
+    a.ev_out[1 + threadIdx.x] =
+        a.virial_acc ? 0.5 * (a.virial_acc[3 * k + l] + a.virial_acc[3 * l + k]) * 627.5094738898777 : 0.0;
+  }
+}
+
+__global__ void finish_force_kernel(const float* __restrict__ fbuf, int n3, double* __restrict__ f_out, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n3) return;
+  const double v = (double)fbuf[i] * 627.5094738898777;
+  f_out[i] = accumulate ? f_out[i] + v : v;
+}
+
+void launch_finish(const FinishArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(finish_energy_kernel, dim3(kFinishBlocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(finish_final_kernel, dim3(1), dim3(256), 0, st, a);
+  const int n3 = a.ntotal * 3;
+  if (n3 > 0 && a.f_out)
+    hipLaunchKernelGGL(finish_force_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, a.fbuf, n3, a.f_out, a.f_accumulate);
+}
+
+}  // namespace ani
