@@ -13,7 +13,7 @@ def load():
         sys.path.insert(0, _ROOT)
     pkg = importlib.import_module("lammps-ani_amd")
     sys.modules["lammps_ani_amd"] = pkg
-    for sub in ("model_file", "harness", "ani_hip"):
+    for sub in ("model_file", "harness", "ani_hip", "comm"):
         mod = importlib.import_module(f"lammps-ani_amd.{sub}")
         sys.modules[f"lammps_ani_amd.{sub}"] = mod
         setattr(pkg, sub, mod)

@@ -102,7 +102,8 @@ int ani_compute_half(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
  *   d_f[ntotal*3]       double; forces are ADDED in place (src/pair_ani_kokkos.cpp:190-191)
  *   d_ev[10]            double; overwritten with {energy, virial[9]} (virial zero unless vflag)
  *   d_eatom[nlocal]     double per-centre energies (overwritten) or NULL
- *   stream              hipStream_t to enqueue on (NULL = the handle's own stream)
+ *   stream              hipStream_t to enqueue on; NULL is the HIP default (null) stream, i.e. the caller's
+ *                       own ordering domain (Kokkos' / torch's default stream), NOT a private stream
  */
 int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_species, const double* d_x,
                             int64_t npairs, const int* d_ilist, const int* d_jlist, const int* d_numneigh, int ago,
@@ -118,6 +119,8 @@ typedef struct {
   int species_count[16];           /* centres per species */
 } ani_debug_view;
 int ani_debug_get(ani_handle* h, ani_debug_view* out);
+/* copy `bytes` from a device pointer of the view to host memory (synchronises the handle's stream first) */
+int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes);
 
 /* kernel timing hooks for bench.py: brackets the AEV / MLP phases of the NEXT computes with hipEvents on the
  * compute stream; ani_phase_times returns accumulated milliseconds {aev_fwd, mlp, aev_bwd, other} and call count. */

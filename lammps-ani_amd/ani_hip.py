@@ -19,7 +19,7 @@ HARTREE2KCALMOL = 627.5094738898777
 
 EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani_use_num_models", "ani_num_species",
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
-           "ani_compute_full_device", "ani_debug_get", "ani_phase_timing", "ani_phase_times"]
+           "ani_compute_full_device", "ani_debug_get", "ani_debug_read", "ani_phase_timing", "ani_phase_times"]
 
 
 class AniError(RuntimeError):
@@ -68,6 +68,7 @@ def lib():
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ani_debug_get.argtypes = [C.c_void_p, C.POINTER(DebugView)]
+        L.ani_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.ani_phase_timing.argtypes = [C.c_void_p, C.c_int]
         L.ani_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _lib = L
@@ -140,6 +141,11 @@ class ANI:
         v = DebugView()
         self._check(self._lib.ani_debug_get(self._h, C.byref(v)))
         return v
+
+    def debug_read(self, d_ptr, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self._check(self._lib.ani_debug_read(self._h, d_ptr, out.ctypes.data, out.nbytes))
+        return out
 
     def phase_timing(self, enable: bool):
         self._check(self._lib.ani_phase_timing(self._h, int(enable)))

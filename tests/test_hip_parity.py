@@ -55,8 +55,6 @@ def test_hip_matches_golden(case, mode, half, model_cache, hip):
 
 def test_hip_aev_matches_oracle(model_cache, hip):
     """The AEV rows themselves (bucketed order) against the oracle's, 1e-5 absolute on values of O(1)."""
-    import ctypes as C
-    import torch
     from oracle import Oracle
     g = load_golden("mixed96_pbc_ani2x_m2")
     inp = golden_input(g)
@@ -66,12 +64,8 @@ def test_hip_aev_matches_oracle(model_cache, hip):
     v = ani.debug_view()
     A = ani.aev_length
     stride = (A + 3) // 4 * 4
-    rows = np.empty(inp.nlocal, dtype=np.int32)
-    aev = np.empty((v.nrows, stride), dtype=np.float32)
-    hipc = C.CDLL("libamdhip64.so")
-    hipc.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    assert hipc.hipMemcpy(rows.ctypes.data, v.d_row_of_centre, rows.nbytes, 2) == 0
-    assert hipc.hipMemcpy(aev.ctypes.data, v.d_aev, aev.nbytes, 2) == 0
+    rows = ani.debug_read(v.d_row_of_centre, inp.nlocal, np.int32)
+    aev = ani.debug_read(v.d_aev, (v.nrows, stride), np.float32)
     ref = Oracle(p).compute(inp, want_aev=True)
     np.testing.assert_allclose(aev[rows, :A], ref["aev"], rtol=0, atol=1e-5)
     # bucket padding rows stay zero
@@ -150,4 +144,43 @@ def test_hip_empty_and_isolated(model_cache, hip):
     got = ani.compute(inp, ago=0)
     _check(got, Oracle(p).compute(inp), 3, "isolated")
     assert np.all(got["force"] == 0)
+    ani.close()
+
+
+def test_hip_device_api_with_torch_plumbing(model_cache, hip):
+    """Device-resident entry point (the Kokkos-overload replacement) driven the way bench.py drives it: torch owns
+    the device memory and the stream, forces are ADDED into d_f, ghosts are folded home by comm.GhostExchange."""
+    import torch
+    from lammps_ani_amd import comm
+    from oracle import Oracle
+    p = model_cache("ani2x", 2, 2024)
+    s = hx.water_box(3000, seed=4)
+    inp = hx.decompose(s, cutoff=5.1, skin=2.0)
+    dev = torch.device("cuda", 0)
+    ani = hip.ANI(p, 0)
+    d_x = torch.from_numpy(inp.x.reshape(-1)).to(dev)
+    d_sp = torch.from_numpy(inp.species.astype(np.int32)).to(dev)
+    d_il, d_nn, d_jl = (torch.from_numpy(a).to(dev) for a in (inp.ilist, inp.numneigh, inp.jlist))
+    d_f = torch.zeros(inp.ntotal * 3, dtype=torch.float64, device=dev)
+    d_ev = torch.zeros(10, dtype=torch.float64, device=dev)
+    d_ea = torch.zeros(inp.nlocal, dtype=torch.float64, device=dev)
+    ex = comm.GhostExchange(inp, s.boxhi - s.boxlo, dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for ago in range(3):
+        d_f.fill_(1.0)  # forces must be accumulated, not overwritten (src/pair_ani_kokkos.cpp:190-191)
+        ani.compute_device(inp.ntotal, inp.nlocal, d_sp.data_ptr(), d_x.data_ptr(), inp.npairs, d_il.data_ptr(),
+                           d_jl.data_ptr(), d_nn.data_ptr(), ago, d_f.data_ptr(), d_ev.data_ptr(), d_ea.data_ptr(),
+                           eflag_atom=True, vflag=True, stream=st)
+        f_raw = d_f.view(-1, 3).clone()
+        ex.reverse_add(d_f.view(-1, 3))
+    torch.cuda.synchronize()
+    ref = Oracle(p).compute(inp)
+    got = dict(energy=float(d_ev[0]), force=f_raw.cpu().numpy() - 1.0, eatom=d_ea.cpu().numpy(),
+               virial=d_ev[1:].cpu().numpy().reshape(3, 3))
+    _check(got, ref, inp.nlocal, "device-api")
+    folded = ref["force"][: inp.nlocal].copy()
+    np.add.at(folded, inp.owner_lidx, ref["force"][inp.nlocal:])
+    # after reverse_add: local rows = 1 + own force + (1 + ghost force) per ghost image folded in
+    nimg = np.bincount(inp.owner_lidx, minlength=inp.nlocal)[:, None]
+    np.testing.assert_allclose(d_f.view(-1, 3)[: inp.nlocal].cpu().numpy() - 1.0 - nimg, folded, rtol=0, atol=F_TOL)
     ani.close()
