@@ -194,8 +194,13 @@ def main():
             f = d_f.view(-1, 3).cpu().numpy()
             fr = ref["force"][: inp.nlocal].copy()
             np.add.at(fr, inp.owner_lidx, ref["force"][inp.nlocal:])
-            out["parity"] = {"max_abs_force_err_kcal_mol_A": float(np.abs(f[: inp.nlocal] - fr).max()),
-                             "energy_err_kcal_mol": float(abs(energy_local - ref["energy"]))}
+            err = np.abs(f[: inp.nlocal] - fr)
+            out["parity"] = {"max_abs_force_err_kcal_mol_A": float(err.max()),
+                             "p999_abs_force_err": float(np.percentile(err, 99.9)),
+                             "rms_force_err": float(np.sqrt((err ** 2).mean())),
+                             "max_abs_force": float(np.abs(fr).max()), "rms_force": float(np.sqrt((fr ** 2).mean())),
+                             "energy_err_kcal_mol": float(abs(energy_local - ref["energy"])),
+                             "tolerance_note": "north_star bar: 1e-4 eV/A = 2.3e-3 kcal/mol/A"}
         print(json.dumps(out))
     ani.close()
     if world > 1:

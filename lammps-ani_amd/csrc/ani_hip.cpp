@@ -77,7 +77,8 @@ struct ani_handle {
   long long npairs = 0;
   int count[kMaxSpecies] = {0}, row_start[kMaxSpecies] = {0};
 
-  DevBuf<int> species, ilist, numneigh, jlist, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
+  int max_numneigh = 0;
+  DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
   DevBuf<float4> xyzs;
   DevBuf<double> x64, f64, ev, eatom, partial, virial_acc;
   DevBuf<float> aev, gaev, act, e_rows, fbuf;
@@ -189,15 +190,18 @@ int rebuild(ani_handle* h, hipStream_t st) {
   HIP_TRY(h, h->nbr_off.reserve((size_t)nlocal + 1));
   HIP_TRY(h, h->row_of_centre.reserve((size_t)2 * nlocal + 2));
   HIP_TRY(h, h->centre_of_row.reserve(nrows_cap));
-  HIP_TRY(h, h->bucket_info.reserve(2 * kMaxSpecies + 2));
+  HIP_TRY(h, h->bucket_info.reserve(kBucketInfoInts));
   PrepOut o{h->nbr_off.p, h->row_of_centre.p, h->centre_of_row.p, h->bucket_info.p};
   launch_prepare(h->species.p, h->ilist.p, h->numneigh.p, nlocal, h->ntotal, m.S, nrows_cap, o, st);
-  int info[2 * kMaxSpecies + 2];
+  int info[kBucketInfoInts];
   HIP_TRY(h, hipMemcpyAsync(info, h->bucket_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
   HIP_TRY(h, hipStreamSynchronize(st));
   if (info[2 * kMaxSpecies + 1]) { h->err = "an atom has a species outside the model's species list (or ilist holds an index outside [0, ntotal))"; return ANI_ERR_ARG; }
   for (int s = 0; s < m.S; s++) { h->count[s] = info[s]; h->row_start[s] = info[kMaxSpecies + s]; }
   h->nrows = info[2 * kMaxSpecies];
+  h->max_numneigh = info[2 * kMaxSpecies + 2];
+  // neighbour segments grouped by species: what lets the AEV kernels accumulate without atomics
+  launch_sort_jlist(h->species.p, h->nbr_off.p, h->numneigh.p, h->jraw.p, h->jlist.p, nlocal, m.S, st);
 
   const size_t stride = h->ap.aev_stride;
   HIP_TRY(h, h->aev.reserve((size_t)std::max(h->nrows, 1) * stride));
@@ -315,11 +319,11 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   a.centre_of_row = h->centre_of_row.p; a.nrows = h->nrows; a.aev = h->aev.p; a.gaev = h->gaev.p; a.fbuf = h->fbuf.p;
   a.virial = vflag ? h->virial_acc.p : nullptr;
   a.err_flag = h->err_flag.p;
-  launch_aev_forward(h->ap, a, st);
+  launch_aev_forward(h->ap, a, h->max_numneigh, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[1], st));
   compute_mlp(h, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[2], st));
-  launch_aev_backward(h->ap, a, st);
+  launch_aev_backward(h->ap, a, h->max_numneigh, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[3], st));
 
   FinishArgs fa{};
@@ -422,7 +426,7 @@ void ani_destroy(ani_handle* h) {
     if (n.w_out) (void)hipFree(n.w_out);
     if (n.b_out) (void)hipFree(n.b_out);
   }
-  h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->nbr_off.release();
+  h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
   h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
   h->xyzs.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->e_rows.release(); h->fbuf.release();
@@ -454,10 +458,11 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
     HIP_TRY(h, h->ilist.reserve(nlocal));
     HIP_TRY(h, h->numneigh.reserve(nlocal));
     HIP_TRY(h, h->jlist.reserve(npairs));
+    HIP_TRY(h, h->jraw.reserve(npairs));
     HIP_TRY(h, hipMemcpyAsync(h->species.p, d_species, sizeof(int) * (size_t)ntotal, hipMemcpyDeviceToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->ilist.p, d_ilist, sizeof(int) * (size_t)nlocal, hipMemcpyDeviceToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, d_numneigh, sizeof(int) * (size_t)nlocal, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(h->jlist.p, d_jlist, sizeof(int) * (size_t)npairs, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->jraw.p, d_jlist, sizeof(int) * (size_t)npairs, hipMemcpyDeviceToDevice, st));
     h->have_list = false;
     rc = rebuild(h, st);
     if (rc) return rc;
@@ -483,10 +488,11 @@ int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
     HIP_TRY(h, h->ilist.reserve(nlocal));
     HIP_TRY(h, h->numneigh.reserve(nlocal));
     HIP_TRY(h, h->jlist.reserve(npairs));
+    HIP_TRY(h, h->jraw.reserve(npairs));
     HIP_TRY(h, hipMemcpyAsync(h->species.p, h->h_species32.data(), sizeof(int) * (size_t)ntotal, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->ilist.p, ilist_unique, sizeof(int) * (size_t)nlocal, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, numneigh, sizeof(int) * (size_t)nlocal, hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemcpyAsync(h->jlist.p, jlist, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->jraw.p, jlist, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice, st));
     h->have_list = false;
     rc = rebuild(h, st);
     if (rc) return rc;

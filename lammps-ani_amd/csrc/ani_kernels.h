@@ -11,6 +11,7 @@ namespace ani {
 constexpr int kRowTile = 128;   // AEV rows per GEMM block; species buckets are padded to this
 constexpr int kMaxRad = 256;    // per-centre capacity of the radial neighbour list held in LDS
 constexpr int kMaxAng = 96;     // per-centre capacity of the angular neighbour list held in LDS
+constexpr int kBucketInfoInts = 2 * kMaxSpecies + 4;
 
 enum Epilogue { EPI_PLAIN = 0, EPI_CELU = 1, EPI_LAST = 2, EPI_BWD = 3 };
 
@@ -43,7 +44,7 @@ struct PrepOut {
   int* nbr_off;         // [nlocal+1] exclusive scan of numneigh
   int* row_of_centre;   // [nlocal]
   int* centre_of_row;   // [nrows_cap] (-1 = padding)
-  int* bucket_info;     // [2*kMaxSpecies + 2]: count[s], row_start[s], nrows, bad_species flag
+  int* bucket_info;     // [kBucketInfoInts]: count[s], row_start[s], nrows, bad_species flag, max numneigh
 };
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
                     const PrepOut& o, hipStream_t st);
@@ -62,8 +63,13 @@ struct AevArgs {
   double* virial;    // backward: [9] (Hartree), atomically added; may be NULL
   int* err_flag;     // set to 1 on LDS capacity overflow
 };
-void launch_aev_forward(const AevParams& p, const AevArgs& a, hipStream_t st);
-void launch_aev_backward(const AevParams& p, const AevArgs& a, hipStream_t st);
+// max_numneigh (known at rebuild) sizes the per-centre LDS neighbour lists of the fast path
+void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st);
+void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st);
+bool aev_fast_path(const AevParams& p, int max_numneigh);
+// rebuild time: stable sort of every centre's neighbour segment by neighbour species (jin -> jout)
+void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_numneigh, const int* d_jin, int* d_jout,
+                       int nlocal, int S, hipStream_t st);
 
 // energy reduction (+ self energies), per-centre energies, force conversion
 struct FinishArgs {

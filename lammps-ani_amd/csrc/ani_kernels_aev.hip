@@ -3,44 +3,553 @@
 // models/lammps_ani.py:277-296) and the autograd pass through it (models/lammps_ani.py:197-206).
 //
 // One wavefront (64 lanes) per centre atom, four centres per workgroup, no workgroup barriers: each wave owns a
-// private LDS region holding the screened neighbour list of its centre and the centre's AEV row (forward) or
-// dE/dAEV row + per-neighbour gradient accumulators (backward).
+// private slice of LDS.  At rebuild time every centre's neighbour segment is sorted by neighbour species
+// (sort_jlist_kernel), so the screened lists built per step come out grouped by species and every
+// (species) / (species pair) block of the AEV row has exactly one contiguous group of contributors.
 //
-//   forward : list pairs are streamed with coalesced jlist loads, positions gathered as float4, screened and
-//             compacted into LDS with ballot/popcount; radial terms are spread over (neighbour, shift) lanes,
-//             angular terms over (j,k) pair lanes; both accumulate into the LDS row, which is then written once.
-//   backward: the same compaction, then dE/dr per neighbour (radial) and dE/d(d_j), dE/d(d_k) per pair
-//             (angular) accumulate into LDS per-neighbour vectors; one global float atomic per neighbour
-//             component scatters the force, the centre gets minus the sum; the virial is reduced per wave.
+// Fast path (NR = 16 radial shifts, NA x NZ = 8x4 (ANI-2x) or 4x8 (ANI-1x) angular grid, <= 8 species):
+//   compaction : coalesced jlist loads, float4 position gathers, ballot/popcount compaction into LDS.
+//   radial     : per species group, lanes = (4 neighbour slots) x (16 shifts); 2 xor-shuffles; plain store.
+//   angular    : the pairs of all non-empty species-pair buckets form ONE padded stream (bucket starts are
+//                multiples of Q = 64/NA).  Per chunk of 64 pairs: phase 1, lane = pair, computes the NA radial
+//                and NZ angular factors once and parks them in LDS; phase 2, lane = (slot q, shift a), walks
+//                the chunk in NA steps with NZ register accumulators that are flushed (log2(Q) xor-shuffles,
+//                plain 16-byte stores) whenever the bucket changes.  No LDS atomics, bitwise reproducible.
+//   backward   : same stream; lane = pair contracts the 32 dE/dAEV entries of its bucket against the factor
+//                derivatives and adds the two gradient vectors to per-neighbour LDS accumulators; one global
+//                float atomic per neighbour component scatters the force; the virial is reduced per wave.
+// Generic path (any NR/NA/NZ/S): the first-generation kernels with LDS float atomics, kept for odd model
+// shapes (e.g. the unit-test "tiny" model).
 //
+// Transcendentals on the fast path are the hardware ones (v_exp_f32, v_log_f32, v_cos_f32, v_sin_f32, v_rcp_f32,
+// v_rsq_f32), as the reference's cuaev is built with -use_fast_math (src/ani_csrc/CMakeLists.txt:12-20).
 // Formulas and their derivatives are the ones restated in oracle/ani_oracle.c.
 #include "ani_kernels.h"
 
 namespace ani {
 
 constexpr int kWaves = 4;
-constexpr int kAevMax = 1024;  // LDS floats reserved for one AEV row (ANI-2x: 1008)
-
-struct WaveLds {
-  float dx[kMaxRad], dy[kMaxRad], dz[kMaxRad], r[kMaxRad], fc[kMaxRad];
-  int sp[kMaxRad], j[kMaxRad];
-  int ang[kMaxAng];
-  float fca[kMaxAng];
-  float row[kAevMax];  // forward: AEV accumulators; backward: dE/dAEV of this centre
-  float gd[3 * kMaxRad];  // backward only
-};
+constexpr int kAevMax = 1024;   // LDS floats reserved for one AEV row (ANI-2x: 1008)
+constexpr int kMaxBuckets = 36; // species pairs on the fast path (S <= 8)
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fcos_rev(float rev) { return __builtin_amdgcn_cosf(rev); }  // cos(2 pi rev)
+__device__ __forceinline__ float fsin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }
+constexpr float kLog2e = 1.4426950408889634f;
 
-// Screen + compact the neighbours of one centre into the wave's LDS region.  Returns counts through nrad/nang
-// (clamped to capacity; *over is set when clamping happened).
+// unordered pair index t -> (a, b), a < b < n, row-major over the strict upper triangle
+__device__ __forceinline__ void decode_pair(int t, int n, int& a, int& b) {
+  const float fn = (float)(2 * n - 1);
+  int aa = (int)floorf((fn - sqrtf(fn * fn - 8.f * (float)t)) * 0.5f);
+  if (aa < 0) aa = 0;
+  if (aa > n - 2) aa = n - 2;
+  while (aa > 0 && aa * (2 * n - aa - 1) / 2 > t) aa--;
+  while ((aa + 1) * (2 * n - aa - 2) / 2 <= t) aa++;
+  a = aa;
+  b = aa + 1 + (t - aa * (2 * n - aa - 1) / 2);
+}
+__device__ __forceinline__ int triu_index(int s1, int s2, int S) {
+  const int lo = s1 < s2 ? s1 : s2, hi = s1 < s2 ? s2 : s1;
+  return lo * S - lo * (lo - 1) / 2 + (hi - lo);
+}
+
+// =====================================================================================================
+// rebuild time: stable sort of every centre's neighbour segment by neighbour species
+// =====================================================================================================
+__global__ __launch_bounds__(256) void sort_jlist_kernel(const int* __restrict__ species, const int* __restrict__ nbr_off,
+                                                         const int* __restrict__ numneigh, const int* __restrict__ jin,
+                                                         int* __restrict__ jout, int nlocal, int S) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ii = blockIdx.x * 4 + wave;
+  if (ii >= nlocal) return;
+  const int beg = nbr_off[ii], n = numneigh[ii];
+  int outpos = 0;
+  for (int s = 0; s < S; s++) {
+    for (int base = 0; base < n; base += 64) {
+      const int q = base + lane;
+      const int j = q < n ? jin[beg + q] : 0;
+      const bool hit = q < n && species[j] == s;
+      const unsigned long long m = __ballot(hit);
+      if (hit) jout[beg + outpos + lanes_below(m)] = j;
+      outpos += __popcll(m);
+    }
+  }
+}
+
+void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_numneigh, const int* d_jin, int* d_jout,
+                       int nlocal, int S, hipStream_t st) {
+  if (nlocal <= 0) return;
+  hipLaunchKernelGGL(sort_jlist_kernel, dim3((nlocal + 3) / 4), dim3(256), 0, st, d_species, d_nbr_off, d_numneigh, d_jin, d_jout,
+                     nlocal, S);
+}
+
+// =====================================================================================================
+// fast path
+// =====================================================================================================
+struct FastLds {
+  // carved from dynamic LDS, per wave; cap = radial capacity (multiple of 64, >= max numneigh)
+  float4* ad;     // [kMaxAng] angular neighbours dx,dy,dz,r
+  float* afc;     // [kMaxAng] fc(r; Rca)
+  int* aidx;      // [kMaxAng] index into the radial list (backward)
+  float* row;     // [kAevMax] forward: AEV row; backward: dE/dAEV row
+  float* pf2;     // [64*NA]
+  float* pf1;     // [64*NZ]
+  int* tb;        // [kMaxBuckets*8] bucket table
+  int* pb;        // [16] output offset of each slot group of the current chunk
+  int* rstart;    // [kMaxSpecies+1]
+  int* astart;    // [kMaxSpecies+1]
+  float* rr;      // [cap]
+  float* rfc;     // [cap]
+  float* rdx;     // [cap] backward
+  float* rdy;
+  float* rdz;
+  int* rj;
+  float* gd;      // [3*cap] backward
+};
+
+__host__ __device__ constexpr int fast_wave_floats(int cap, bool bwd) {
+  // ad 4*kMaxAng + afc kMaxAng + aidx kMaxAng + row kAevMax + pf 64*12 + tb kMaxBuckets*8 + pb 16 + starts 2*(kMaxSpecies+1)(->48)
+  return 6 * kMaxAng + kAevMax + 64 * 12 + kMaxBuckets * 8 + 16 + 48 + (bwd ? 9 * cap : 2 * cap);
+}
+
+template <int NA, int NZ>
+__device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd) {
+  FastLds L;
+  float* p = base;
+  L.ad = reinterpret_cast<float4*>(p); p += 4 * kMaxAng;
+  L.row = p; p += kAevMax;
+  L.pf2 = p; p += 64 * NA;
+  L.pf1 = p; p += 64 * NZ;
+  L.tb = reinterpret_cast<int*>(p); p += kMaxBuckets * 8;
+  L.afc = p; p += kMaxAng;
+  L.aidx = reinterpret_cast<int*>(p); p += kMaxAng;
+  L.pb = reinterpret_cast<int*>(p); p += 16;
+  L.rstart = reinterpret_cast<int*>(p); p += 24;
+  L.astart = reinterpret_cast<int*>(p); p += 24;
+  L.rr = p; p += cap;
+  L.rfc = p; p += cap;
+  if (bwd) {
+    L.rdx = p; p += cap;
+    L.rdy = p; p += cap;
+    L.rdz = p; p += cap;
+    L.rj = reinterpret_cast<int*>(p); p += cap;
+    L.gd = p; p += 3 * cap;
+  } else {
+    L.rdx = L.rdy = L.rdz = L.gd = nullptr;
+    L.rj = nullptr;
+  }
+  return L;
+}
+
+// Screen + compact the (species-sorted) neighbours of centre ii.  Lane s (< S) leaves with the number of radial /
+// angular neighbours of species s in cr / ca; group starts are written to L.rstart / L.astart.
+template <bool BWD>
+__device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs& a, int ii, int lane, int cap, FastLds& L,
+                                               int& nrad, int& nang, bool& over) {
+  const int i = a.ilist[ii];
+  const float4 xi = a.xyzs[i];
+  const int beg = a.nbr_off[ii];
+  const int n = a.numneigh[ii];
+  nrad = 0;
+  nang = 0;
+  over = false;
+  int cr = 0, ca = 0;  // lane s: count of species s
+  const float half_inv_Rcr = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;  // r/(2 Rcr) revolutions
+  const float half_inv_Rca = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
+  for (int base = 0; base < n; base += 64) {
+    const int q = base + lane;
+    const bool valid = q < n;
+    const int j = valid ? a.jlist[beg + q] : i;
+    const float4 xj = a.xyzs[j];
+    const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+    const float r2 = dx * dx + dy * dy + dz * dz;
+    const float r = __builtin_amdgcn_sqrtf(r2);
+    const int sp = __float_as_int(xj.w);
+    const bool in_r = valid && (p.compat || r <= p.Rcr);
+    const bool in_a = valid && r <= p.Rca;
+    const unsigned long long mr = __ballot(in_r);
+    const unsigned long long ma = __ballot(in_a);
+    const int pos = nrad + lanes_below(mr);
+    if (in_r && pos < cap) {
+      L.rr[pos] = r;
+      L.rfc[pos] = 0.5f * fcos_rev(r * half_inv_Rcr) + 0.5f;
+      if (BWD) { L.rdx[pos] = dx; L.rdy[pos] = dy; L.rdz[pos] = dz; L.rj[pos] = j; }
+    }
+    const int posa = nang + lanes_below(ma);
+    if (in_a && posa < kMaxAng) {
+      L.ad[posa] = make_float4(dx, dy, dz, r);
+      L.afc[posa] = 0.5f * fcos_rev(r * half_inv_Rca) + 0.5f;
+      if (BWD) L.aidx[posa] = pos;
+    }
+    for (int s = 0; s < p.S; s++) {
+      const int c1 = __popcll(__ballot(in_r && sp == s));
+      const int c2 = __popcll(__ballot(in_a && sp == s));
+      if (lane == s) { cr += c1; ca += c2; }
+    }
+    nrad += __popcll(mr);
+    nang += __popcll(ma);
+  }
+  if (nrad > cap) { nrad = cap; over = true; }
+  if (nang > kMaxAng) { nang = kMaxAng; over = true; }
+  // exclusive prefix over species (lanes 0..S-1), S <= 16
+  int er = cr, ea = ca;
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) {
+    const int t1 = __shfl_up(er, off), t2 = __shfl_up(ea, off);
+    if (lane >= off) { er += t1; ea += t2; }
+  }
+  if (lane <= p.S) {
+    // lane s holds inclusive sums; start[s] = incl - count ; start[S] = total
+    if (lane < p.S) { L.rstart[lane] = min(er - cr, cap); L.astart[lane] = min(ea - ca, kMaxAng); }
+    else { L.rstart[lane] = nrad; L.astart[lane] = nang; }
+  }
+}
+
+// Build the table of non-empty species-pair buckets.  Returns the padded stream length; nbk = number of entries.
+// entry: {tstart, a1, n1, a2, n2, outoff, tri, npairs}
+template <int NA, int NZ>
+__device__ __forceinline__ int build_bucket_table(const AevParams& p, int lane, FastLds& L, int& nbk) {
+  constexpr int Q = 64 / NA;
+  const int nb_all = p.S * (p.S + 1) / 2;
+  int s1 = 0, s2 = 0, np = 0, n1 = 0, n2 = 0;
+  if (lane < nb_all) {
+    int rem = lane;
+    while (rem >= p.S - s1) { rem -= p.S - s1; s1++; }
+    s2 = s1 + rem;
+    n1 = L.astart[s1 + 1] - L.astart[s1];
+    n2 = L.astart[s2 + 1] - L.astart[s2];
+    np = (s1 == s2) ? n1 * (n1 - 1) / 2 : n1 * n2;
+  }
+  const int npad = (np + Q - 1) / Q * Q;
+  int incl = npad;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  const unsigned long long m = __ballot(np > 0);
+  if (np > 0) {
+    int* e = L.tb + 8 * lanes_below(m);
+    e[0] = incl - npad; e[1] = L.astart[s1]; e[2] = n1; e[3] = L.astart[s2]; e[4] = n2;
+    e[5] = p.radial_len + lane * (NA * NZ); e[6] = (s1 == s2) ? 1 : 0; e[7] = np;
+  }
+  nbk = __popcll(m);
+  return __shfl(incl, 63);
+}
+
+// lane -> its pair of the padded stream.  valid = false for padding slots (indices then point at neighbour 0 of
+// the group, a harmless geometry).
+__device__ __forceinline__ void stream_pair(const FastLds& L, int nbk, int t, int& ia, int& ib, int& outoff, bool& valid) {
+  int e = 0;
+  for (int k = 1; k < nbk; k++)
+    if (t >= L.tb[8 * k]) e = k;
+  const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);
+  const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);
+  const int u = t - e0.x;
+  valid = u < e1.w;
+  outoff = e1.y;
+  int a = 0, b = 0;
+  if (valid) {
+    if (e1.z) {
+      decode_pair(u, e0.z, a, b);
+    } else {
+      a = (int)(((float)u + 0.5f) * frcp((float)e1.x));
+      b = u - a * e1.x;
+    }
+  } else if (e1.z) {
+    b = 1;  // distinct neighbours keep the padded geometry finite
+  }
+  ia = e0.y + a;
+  ib = e0.w + b;
+}
+
+template <int NA, int NZ>
+__global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, AevArgs a, int cap) {
+  extern __shared__ float4 smem4[];
+  constexpr int NR = 16, Q = 64 / NA;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kWaves + wave;
+  if (row >= a.nrows) return;
+  const int ii = a.centre_of_row[row];
+  if (ii < 0) return;  // bucket padding: row stays zero (cleared at rebuild)
+  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, false), cap, false);
+
+  for (int e = lane; e < kAevMax / 4; e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
+  int nrad, nang;
+  bool over;
+  compact_sorted<false>(p, a, ii, lane, cap, L, nrad, nang, over);
+  if (over && lane == 0) atomicOr(a.err_flag, 1);
+  wave_sync();
+
+  // ---- radial: per species group, lanes = (slot q, shift k) ----
+  {
+    const int q = lane >> 4, k = lane & 15;
+    const float shf = p.ShfR[k];
+    const float c = -p.EtaR * kLog2e;
+    for (int s = 0; s < p.S; s++) {
+      const int b0 = L.rstart[s], b1 = L.rstart[s + 1];
+      if (b1 <= b0) continue;
+      float acc = 0.f;
+      for (int t = b0 + q; t < b1; t += 4) {
+        const float dr = L.rr[t] - shf;
+        acc = fmaf(fexp2(c * dr * dr), L.rfc[t], acc);
+      }
+      acc += __shfl_xor(acc, 16);
+      acc += __shfl_xor(acc, 32);
+      if (q == 0) L.row[s * NR + k] = 0.25f * acc;
+    }
+  }
+
+  // ---- angular ----
+  int nbk;
+  const int total = build_bucket_table<NA, NZ>(p, lane, L, nbk);
+  wave_sync();
+  float acc[NZ];
+#pragma unroll
+  for (int z = 0; z < NZ; z++) acc[z] = 0.f;
+  int cur_off = -1;
+  const int la = lane % NA, lq = lane / NA;
+  const float cA = -p.EtaA * kLog2e;
+
+  auto flush = [&]() {
+    if (cur_off >= 0) {
+#pragma unroll
+      for (int z = 0; z < NZ; z++) {
+        float v = acc[z];
+#pragma unroll
+        for (int off = NA; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        acc[z] = v;
+      }
+      if (lq == 0) {
+#pragma unroll
+        for (int z = 0; z < NZ; z++) L.row[cur_off + la * NZ + z] = acc[z];
+      }
+    }
+#pragma unroll
+    for (int z = 0; z < NZ; z++) acc[z] = 0.f;
+  };
+
+  for (int base = 0; base < total; base += 64) {
+    // phase 1: lane = pair
+    {
+      int ia, ib, outoff;
+      bool valid;
+      stream_pair(L, nbk, base + lane, ia, ib, outoff, valid);
+      const float4 A = L.ad[ia], B = L.ad[ib];
+      const float dot = A.x * B.x + A.y * B.y + A.z * B.z;
+      const float cth = 0.95f * dot * frcp(fmaxf(A.w * B.w, 1e-10f));
+      const float sth = __builtin_amdgcn_sqrtf(fmaxf(1.f - cth * cth, 0.f));
+      const float w = valid ? 2.f * L.afc[ia] * L.afc[ib] : 0.f;
+      const float rho = 0.5f * (A.w + B.w);
+#pragma unroll
+      for (int z = 0; z < NZ; z++) {
+        const float basez = fmaxf(0.5f * (1.f + cth * p.cosZ[z] + sth * p.sinZ[z]), 0.f);
+        L.pf1[lane * NZ + z] = w * fexp2(p.Zeta * flog2(basez));
+      }
+#pragma unroll
+      for (int s = 0; s < NA; s++) {
+        const float dr = rho - p.ShfA[s];
+        L.pf2[lane * NA + s] = fexp2(cA * dr * dr);
+      }
+      if ((lane % Q) == 0) L.pb[lane / Q] = outoff;
+    }
+    wave_sync();
+    // phase 2: lane = (slot lq, shift la); group g covers slots g*Q .. g*Q+Q-1, all of one bucket
+    const int ngroups = min(NA, (total - base + Q - 1) / Q);
+    for (int g = 0; g < ngroups; g++) {
+      const int off = __builtin_amdgcn_readfirstlane(L.pb[g]);
+      if (off != cur_off) { flush(); cur_off = off; }
+      const int slot = g * Q + lq;
+      const float f2 = L.pf2[slot * NA + la];
+#pragma unroll
+      for (int z = 0; z < NZ; z++) acc[z] = fmaf(f2, L.pf1[slot * NZ + z], acc[z]);
+    }
+    wave_sync();
+  }
+  flush();
+  wave_sync();
+
+  float4* dst = reinterpret_cast<float4*>(a.aev + (long long)row * p.aev_stride);
+  const int n4 = p.aev_stride >> 2;
+  for (int e = lane; e < n4; e += 64) dst[e] = reinterpret_cast<const float4*>(L.row)[e];
+}
+
+template <int NA, int NZ>
+__global__ __launch_bounds__(64 * kWaves) void aev_backward_fast(AevParams p, AevArgs a, int cap) {
+  extern __shared__ float4 smem4[];
+  constexpr int NR = 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * kWaves + wave;
+  if (row >= a.nrows) return;
+  const int ii = a.centre_of_row[row];
+  if (ii < 0) return;
+  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, true), cap, true);
+
+  {
+    const float4* g4 = reinterpret_cast<const float4*>(a.gaev + (long long)row * p.aev_stride);
+    const int n4 = p.aev_stride >> 2;
+    for (int e = lane; e < n4; e += 64) reinterpret_cast<float4*>(L.row)[e] = g4[e];
+  }
+  int nrad, nang;
+  bool over;
+  compact_sorted<true>(p, a, ii, lane, cap, L, nrad, nang, over);
+  if (over && lane == 0) atomicOr(a.err_flag, 1);
+  wave_sync();
+
+  // ---- radial: one lane per neighbour ----
+  {
+    const float cR = -p.EtaR * kLog2e;
+    const float rev = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;
+    for (int s = 0; s < p.S; s++) {
+      const int b0 = L.rstart[s], b1 = L.rstart[s + 1];
+      const float* gg = L.row + s * NR;
+      for (int t = b0 + lane; t < b1; t += 64) {
+        const float r = L.rr[t], fc = L.rfc[t];
+        const float dfc = -0.5f * p.pi_over_Rcr * fsin_rev(r * rev);
+        float dEdr = 0.f;
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+          const float dr = r - p.ShfR[k];
+          const float e = fexp2(cR * dr * dr);
+          dEdr = fmaf(gg[k] * e, fmaf(-2.f * p.EtaR * dr, fc, dfc), dEdr);
+        }
+        const float sc = 0.25f * dEdr * frcp(r);
+        L.gd[3 * t + 0] = sc * L.rdx[t];
+        L.gd[3 * t + 1] = sc * L.rdy[t];
+        L.gd[3 * t + 2] = sc * L.rdz[t];
+      }
+    }
+  }
+  int nbk;
+  const int total = build_bucket_table<NA, NZ>(p, lane, L, nbk);
+  wave_sync();
+
+  // ---- angular: lane = pair of the padded stream ----
+  const float cA = -p.EtaA * kLog2e;
+  const float revA = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
+  for (int base = 0; base < total; base += 64) {
+    int ia, ib, outoff;
+    bool valid;
+    stream_pair(L, nbk, base + lane, ia, ib, outoff, valid);
+    const float4 A = L.ad[ia], B = L.ad[ib];
+    const float inv_ra = frcp(A.w), inv_rb = frcp(B.w);
+    const float inv_rr = inv_ra * inv_rb;
+    const float cosv = (A.x * B.x + A.y * B.y + A.z * B.z) * inv_rr;
+    const float c = 0.95f * cosv;
+    const float s2 = fmaxf(1.f - c * c, 1e-12f);
+    const float inv_s = frsq(s2);
+    const float s = s2 * inv_s;
+    const float fa = L.afc[ia], fb = L.afc[ib];
+    const float dfa = -0.5f * p.pi_over_Rca * fsin_rev(A.w * revA);
+    const float dfb = -0.5f * p.pi_over_Rca * fsin_rev(B.w * revA);
+    const float rho = 0.5f * (A.w + B.w);
+    float f1[NZ], df1[NZ];
+#pragma unroll
+    for (int z = 0; z < NZ; z++) {
+      const float bz = fmaxf(0.5f * (1.f + c * p.cosZ[z] + s * p.sinZ[z]), 0.f);
+      const float pm1 = fexp2((p.Zeta - 1.f) * flog2(bz));
+      f1[z] = pm1 * bz;
+      df1[z] = p.Zeta * pm1 * 0.5f * (s * p.cosZ[z] - c * p.sinZ[z]) * inv_s;
+    }
+    const float* gg = L.row + outoff;
+    float Aq = 0.f, Bq = 0.f, Cq = 0.f;
+#pragma unroll
+    for (int sa = 0; sa < NA; sa++) {
+      const float dr = rho - p.ShfA[sa];
+      const float f2 = fexp2(cA * dr * dr);
+      const float df2 = -2.f * p.EtaA * dr * f2;
+      float g1 = 0.f, gd1 = 0.f;
+#pragma unroll
+      for (int z = 0; z < NZ; z++) {
+        const float gv = gg[sa * NZ + z];
+        g1 = fmaf(gv, f1[z], g1);
+        gd1 = fmaf(gv, df1[z], gd1);
+      }
+      Aq = fmaf(f2, gd1, Aq);
+      Cq = fmaf(f2, g1, Cq);
+      Bq = fmaf(df2, g1, Bq);
+    }
+    if (valid) {
+      const float P = fa * fb;
+      Aq *= 2.f * P * 0.95f;
+      Bq *= P;       // 2 * P * 0.5
+      Cq *= 2.f;
+      const float ca = Aq * inv_rr;
+      const float ta = (Bq + Cq * dfa * fb) * inv_ra - Aq * cosv * inv_ra * inv_ra;
+      const float tb = (Bq + Cq * fa * dfb) * inv_rb - Aq * cosv * inv_rb * inv_rb;
+      const int qa = L.aidx[ia], qb = L.aidx[ib];
+      atomicAdd(&L.gd[3 * qa + 0], ca * B.x + ta * A.x);
+      atomicAdd(&L.gd[3 * qa + 1], ca * B.y + ta * A.y);
+      atomicAdd(&L.gd[3 * qa + 2], ca * B.z + ta * A.z);
+      atomicAdd(&L.gd[3 * qb + 0], ca * A.x + tb * B.x);
+      atomicAdd(&L.gd[3 * qb + 1], ca * A.y + tb * B.y);
+      atomicAdd(&L.gd[3 * qb + 2], ca * A.z + tb * B.z);
+    }
+  }
+  wave_sync();
+
+  // ---- scatter: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d ----
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = lane; q < nrad; q += 64) {
+    const float gx = L.gd[3 * q], gy = L.gd[3 * q + 1], gz = L.gd[3 * q + 2];
+    const int j = L.rj[q];
+    atomicAdd(&a.fbuf[3 * j + 0], -gx);
+    atomicAdd(&a.fbuf[3 * j + 1], -gy);
+    atomicAdd(&a.fbuf[3 * j + 2], -gz);
+    fx += gx; fy += gy; fz += gz;
+    if (a.virial) {
+      const float dx = L.rdx[q], dy = L.rdy[q], dz = L.rdz[q];
+      v[0] += gx * dx; v[1] += gx * dy; v[2] += gx * dz;
+      v[3] += gy * dx; v[4] += gy * dy; v[5] += gy * dz;
+      v[6] += gz * dx; v[7] += gz * dy; v[8] += gz * dz;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    fx += __shfl_xor(fx, off);
+    fy += __shfl_xor(fy, off);
+    fz += __shfl_xor(fz, off);
+  }
+  const int i = a.ilist[ii];
+  if (lane == 0) {
+    atomicAdd(&a.fbuf[3 * i + 0], fx);
+    atomicAdd(&a.fbuf[3 * i + 1], fy);
+    atomicAdd(&a.fbuf[3 * i + 2], fz);
+  }
+  if (a.virial) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      float sv = v[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off);
+      if (lane == 0) atomicAdd(&a.virial[k], -(double)sv);
+    }
+  }
+}
+
+// =====================================================================================================
+// generic path (any model shape): LDS float atomics, precise libm transcendentals
+// =====================================================================================================
+struct WaveLds {
+  float dx[kMaxRad], dy[kMaxRad], dz[kMaxRad], r[kMaxRad], fc[kMaxRad];
+  int sp[kMaxRad], j[kMaxRad];
+  int ang[kMaxAng];
+  float fca[kMaxAng];
+  float row[kAevMax];
+  float gd[3 * kMaxRad];
+};
+
 __device__ __forceinline__ void compact_neighbours(const AevParams& p, const AevArgs& a, int ii, int lane, WaveLds& L,
                                                    int& nrad, int& nang, bool& over) {
   const int i = a.ilist[ii];
@@ -80,31 +589,13 @@ __device__ __forceinline__ void compact_neighbours(const AevParams& p, const Aev
   if (nang > kMaxAng) { nang = kMaxAng; over = true; }
 }
 
-// unordered pair index t -> (a, b), a < b < n, row-major over the strict upper triangle
-__device__ __forceinline__ void decode_pair(int t, int n, int& a, int& b) {
-  const float fn = (float)(2 * n - 1);
-  int aa = (int)floorf((fn - sqrtf(fn * fn - 8.f * (float)t)) * 0.5f);
-  if (aa < 0) aa = 0;
-  if (aa > n - 2) aa = n - 2;
-  // first pair index of row aa: aa*(2n-aa-1)/2
-  while (aa > 0 && aa * (2 * n - aa - 1) / 2 > t) aa--;
-  while ((aa + 1) * (2 * n - aa - 2) / 2 <= t) aa++;
-  a = aa;
-  b = aa + 1 + (t - aa * (2 * n - aa - 1) / 2);
-}
-
-__device__ __forceinline__ int triu_index(int s1, int s2, int S) {
-  const int lo = s1 < s2 ? s1 : s2, hi = s1 < s2 ? s2 : s1;
-  return lo * S - lo * (lo - 1) / 2 + (hi - lo);
-}
-
-__global__ __launch_bounds__(64 * kWaves) void aev_forward_kernel(AevParams p, AevArgs a) {
+__global__ __launch_bounds__(64 * kWaves) void aev_forward_generic(AevParams p, AevArgs a) {
   __shared__ WaveLds lds[kWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * kWaves + wave;
   if (row >= a.nrows) return;
   const int ii = a.centre_of_row[row];
-  if (ii < 0) return;  // bucket padding: row stays zero (cleared at rebuild)
+  if (ii < 0) return;
   WaveLds& L = lds[wave];
 
   for (int e = lane; e < p.aev_stride; e += 64) L.row[e] = 0.f;
@@ -114,7 +605,6 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_kernel(AevParams p, A
   if (over && lane == 0) atomicOr(a.err_flag, 1);
   wave_sync();
 
-  // radial: items (neighbour q, shift k)
   const int nR = p.nR;
   for (int t = lane; t < nrad * nR; t += 64) {
     const int q = t / nR, k = t - q * nR;
@@ -122,8 +612,6 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_kernel(AevParams p, A
     const float v = 0.25f * expf(-p.EtaR * dr * dr) * L.fc[q];
     atomicAdd(&L.row[L.sp[q] * nR + k], v);
   }
-
-  // angular: items = unordered pairs of the angular list
   const int npair = nang * (nang - 1) / 2;
   for (int t = lane; t < npair; t += 64) {
     int ia, ib;
@@ -137,7 +625,6 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_kernel(AevParams p, A
     const float rho = 0.5f * (ra + rb);
     float* out = &L.row[p.radial_len + triu_index(L.sp[qa], L.sp[qb], p.S) * p.nAZ];
     float f1[kMaxShfZ];
-#pragma unroll 4
     for (int z = 0; z < p.nZ; z++) {
       const float base = 0.5f * (1.f + c * p.cosZ[z] + s * p.sinZ[z]);
       f1[z] = w * powf(fmaxf(base, 0.f), p.Zeta);
@@ -153,7 +640,7 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_kernel(AevParams p, A
   for (int e = lane; e < p.aev_stride; e += 64) dst[e] = L.row[e];
 }
 
-__global__ __launch_bounds__(64 * kWaves) void aev_backward_kernel(AevParams p, AevArgs a) {
+__global__ __launch_bounds__(64 * kWaves) void aev_backward_generic(AevParams p, AevArgs a) {
   __shared__ WaveLds lds[kWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * kWaves + wave;
@@ -170,7 +657,6 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_kernel(AevParams p, 
   if (over && lane == 0) atomicOr(a.err_flag, 1);
   wave_sync();
 
-  // radial: one lane per neighbour, dE/dr summed over shifts
   const int nR = p.nR;
   for (int q = lane; q < nrad; q += 64) {
     const float r = L.r[q], fc = L.fc[q];
@@ -189,7 +675,6 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_kernel(AevParams p, 
   }
   wave_sync();
 
-  // angular: one lane per unordered pair
   const int npair = nang * (nang - 1) / 2;
   for (int t = lane; t < npair; t += 64) {
     int ia, ib;
@@ -208,9 +693,7 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_kernel(AevParams p, 
     const float P = fa * fb, rho = 0.5f * (ra + rb);
     const float* gg = &L.row[p.radial_len + triu_index(L.sp[qa], L.sp[qb], p.S) * p.nAZ];
     float f1[kMaxShfZ], df1[kMaxShfZ];
-#pragma unroll 4
     for (int z = 0; z < p.nZ; z++) {
-      // base = (1 + cos(theta - ShfZ))/2 ; sin(theta - ShfZ) = s cosZ - c sinZ
       const float base = fmaxf(0.5f * (1.f + c * p.cosZ[z] + s * p.sinZ[z]), 0.f);
       const float pm1 = powf(base, p.Zeta - 1.f);
       f1[z] = pm1 * base;
@@ -242,7 +725,6 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_kernel(AevParams p, 
   }
   wave_sync();
 
-  // scatter: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d
   float fx = 0.f, fy = 0.f, fz = 0.f;
   float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int q = lane; q < nrad; q += 64) {
@@ -274,21 +756,71 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_kernel(AevParams p, 
   if (a.virial) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-      float s = v[k];
+      float sv = v[k];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (lane == 0) atomicAdd(&a.virial[k], -(double)s);
+      for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off);
+      if (lane == 0) atomicAdd(&a.virial[k], -(double)sv);
     }
   }
 }
 
-void launch_aev_forward(const AevParams& p, const AevArgs& a, hipStream_t st) {
-  if (a.nrows <= 0) return;
-  hipLaunchKernelGGL(aev_forward_kernel, dim3((a.nrows + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, st, p, a);
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+static int fast_kind(const AevParams& p) {
+  if (p.nR != 16 || p.S > 8 || (p.aev_stride & 3)) return 0;
+  if (p.nA == 8 && p.nZ == 4) return 1;
+  if (p.nA == 4 && p.nZ == 8) return 2;
+  return 0;
 }
-void launch_aev_backward(const AevParams& p, const AevArgs& a, hipStream_t st) {
+
+bool aev_fast_path(const AevParams& p, int max_numneigh) {
+  if (!fast_kind(p)) return false;
+  const int cap = (max_numneigh + 63) / 64 * 64;
+  // one wave's slice of the backward kernel must fit in 160 KB / kWaves
+  return (size_t)fast_wave_floats(cap < 64 ? 64 : cap, true) * 4 * kWaves <= 160 * 1024;
+}
+
+void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
   if (a.nrows <= 0) return;
-  hipLaunchKernelGGL(aev_backward_kernel, dim3((a.nrows + kWaves - 1) / kWaves), dim3(64 * kWaves), 0, st, p, a);
+  const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
+  if (aev_fast_path(p, max_numneigh)) {
+    int cap = (max_numneigh + 63) / 64 * 64;
+    if (cap < 64) cap = 64;
+    const size_t lds = (size_t)fast_wave_floats(cap, false) * 4 * kWaves;
+    if (fast_kind(p) == 1) {
+      static bool once = (hipFuncSetAttribute((const void*)aev_forward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      (void)once;
+      hipLaunchKernelGGL((aev_forward_fast<8, 4>), grid, block, lds, st, p, a, cap);
+    } else {
+      static bool once = (hipFuncSetAttribute((const void*)aev_forward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      (void)once;
+      hipLaunchKernelGGL((aev_forward_fast<4, 8>), grid, block, lds, st, p, a, cap);
+    }
+  } else {
+    hipLaunchKernelGGL(aev_forward_generic, grid, block, 0, st, p, a);
+  }
+}
+
+void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
+  if (a.nrows <= 0) return;
+  const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
+  if (aev_fast_path(p, max_numneigh)) {
+    int cap = (max_numneigh + 63) / 64 * 64;
+    if (cap < 64) cap = 64;
+    const size_t lds = (size_t)fast_wave_floats(cap, true) * 4 * kWaves;
+    if (fast_kind(p) == 1) {
+      static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      (void)once;
+      hipLaunchKernelGGL((aev_backward_fast<8, 4>), grid, block, lds, st, p, a, cap);
+    } else {
+      static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      (void)once;
+      hipLaunchKernelGGL((aev_backward_fast<4, 8>), grid, block, lds, st, p, a, cap);
+    }
+  } else {
+    hipLaunchKernelGGL(aev_backward_generic, grid, block, 0, st, p, a);
+  }
 }
 
 }  // namespace ani

@@ -49,15 +49,18 @@ __global__ __launch_bounds__(1024) void prepare_count_kernel(const int* __restri
   __shared__ int wave_sums[16];
   int carry = 0;
   if (blockIdx.x == 0) {
+    int vmax = 0;
     for (int base = 0; base < nlocal; base += blockDim.x) {
       const int ii = base + threadIdx.x;
       const int v = ii < nlocal ? numneigh[ii] : 0;
+      vmax = v > vmax ? v : vmax;
       int total;
       const int ex = block_exclusive_scan(v, total, wave_sums);
       if (ii < nlocal) o.nbr_off[ii] = carry + ex;
       carry += total;
     }
     if (threadIdx.x == 0) o.nbr_off[nlocal] = carry;
+    atomicMax(&o.bucket_info[2 * kMaxSpecies + 2], vmax);
   } else if ((int)blockIdx.x <= S) {
     const int s = blockIdx.x - 1;
     for (int base = 0; base < nlocal; base += blockDim.x) {
@@ -115,7 +118,7 @@ void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numne
   // row_of_centre is sized 2*nlocal by the caller: the second half is the rank-in-species scratch
   int* rank = o.row_of_centre + nlocal;
   (void)hipMemsetAsync(o.centre_of_row, 0xff, sizeof(int) * (size_t)nrows_cap, st);
-  (void)hipMemsetAsync(o.bucket_info, 0, sizeof(int) * (2 * kMaxSpecies + 2), st);
+  (void)hipMemsetAsync(o.bucket_info, 0, sizeof(int) * kBucketInfoInts, st);
   hipLaunchKernelGGL(prepare_count_kernel, dim3(S + 2), dim3(1024), 0, st, d_species, d_ilist, d_numneigh, nlocal, ntotal, S, o, rank);
   if (nlocal > 0)
     hipLaunchKernelGGL(prepare_rows_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, st, d_species, d_ilist, nlocal, S,

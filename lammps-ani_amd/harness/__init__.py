@@ -170,10 +170,15 @@ def read_lammps_data(path: str) -> System:
     return System(arr[:, 2:5].astype(np.float64).copy(), arr[:, 1].astype(np.int32), lo, hi)
 
 
-def water_box(n_atoms: int, seed: int = 12345, density: float = 0.98, type_H: int = 1, type_O: int = 4) -> System:
+def water_box(n_atoms: int, seed: int = 12345, density: float = 0.98, type_H: int = 1, type_O: int = 4,
+              min_oo: float = 2.4, min_contact: float = 1.4) -> System:
     """Synthetic liquid-water-like box: n_atoms/3 rigid waters (r_OH 0.9572 A, 104.52 deg),
-    random orientation, centres on a jittered simple-cubic lattice, density as in
-    examples/benchmark/data/water/prepare/generate_pdb.py:29-48 (0.98 g/cm^3).  Atom order O,H,H per molecule."""
+    centres on a jittered simple-cubic lattice (sigma 0.3 A, O-O >= min_oo), random orientations re-drawn until no
+    intermolecular pair is closer than min_contact; density as in
+    examples/benchmark/data/water/prepare/generate_pdb.py:29-48 (0.98 g/cm^3).  Atom order O,H,H per molecule.
+    Without the two rejections a few pairs per 10^4 atoms sit at 0.4-0.6 A and carry forces of 10^3 kcal/mol/A,
+    which no equilibrated water box has."""
+    from scipy.spatial import cKDTree
     assert n_atoms % 3 == 0
     nmol = n_atoms // 3
     mass_g = nmol * (15.999 + 2 * 1.008) / 6.0221408e23
@@ -182,27 +187,51 @@ def water_box(n_atoms: int, seed: int = 12345, density: float = 0.98, type_H: in
     ncell = int(np.ceil(nmol ** (1.0 / 3.0)))
     a = L / ncell
     idx = rng.permutation(ncell ** 3)[:nmol]
-    ix, iy, iz = idx % ncell, (idx // ncell) % ncell, idx // (ncell * ncell)
-    centres = (np.stack([ix, iy, iz], 1) + 0.5) * a + rng.normal(0.0, 0.25, size=(nmol, 3))
-    # random rotations from normalised quaternions
-    q = rng.normal(size=(nmol, 4))
-    q /= np.linalg.norm(q, axis=1, keepdims=True)
-    w, xq, yq, zq = q.T
-    R = np.stack([
-        np.stack([1 - 2 * (yq * yq + zq * zq), 2 * (xq * yq - zq * w), 2 * (xq * zq + yq * w)], 1),
-        np.stack([2 * (xq * yq + zq * w), 1 - 2 * (xq * xq + zq * zq), 2 * (yq * zq - xq * w)], 1),
-        np.stack([2 * (xq * zq - yq * w), 2 * (yq * zq + xq * w), 1 - 2 * (xq * xq + yq * yq)], 1)], 1)
+    site = (np.stack([idx % ncell, (idx // ncell) % ncell, idx // (ncell * ncell)], 1) + 0.5) * a
+    centres = site + rng.normal(0.0, 0.3, size=(nmol, 3))
+    for _ in range(500):
+        w = np.mod(centres, L)
+        w[w >= L] = 0.0
+        pairs = cKDTree(w, boxsize=L).query_pairs(min_oo, output_type="ndarray")
+        if len(pairs) == 0:
+            break
+        redo = np.unique(pairs[:, 1])
+        centres[redo] = site[redo] + rng.normal(0.0, 0.3, size=(len(redo), 3))
+
     roh, ang = 0.9572, np.deg2rad(104.52)
     h1 = np.array([roh * np.sin(ang / 2), roh * np.cos(ang / 2), 0.0])
     h2 = np.array([-roh * np.sin(ang / 2), roh * np.cos(ang / 2), 0.0])
-    pos = np.empty((nmol, 3, 3))
-    pos[:, 0] = centres
-    pos[:, 1] = centres + R @ h1
-    pos[:, 2] = centres + R @ h2
-    x = pos.reshape(-1, 3) - L / 2
-    types = np.tile(np.array([type_O, type_H, type_H], dtype=np.int32), nmol)
+
+    def random_rotations(k):
+        q = rng.normal(size=(k, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        w_, x_, y_, z_ = q.T
+        return np.stack([
+            np.stack([1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - z_ * w_), 2 * (x_ * z_ + y_ * w_)], 1),
+            np.stack([2 * (x_ * y_ + z_ * w_), 1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - x_ * w_)], 1),
+            np.stack([2 * (x_ * z_ - y_ * w_), 2 * (y_ * z_ + x_ * w_), 1 - 2 * (x_ * x_ + y_ * y_)], 1)], 1)
+
+    def place(Rm, c):
+        out = np.empty((len(c), 3, 3))
+        out[:, 0] = c
+        out[:, 1] = c + Rm @ h1
+        out[:, 2] = c + Rm @ h2
+        return out
+
+    pos = place(random_rotations(nmol), centres)
+    for _ in range(500):
+        flat = np.mod(pos.reshape(-1, 3), L)
+        flat[flat >= L] = 0.0
+        pairs = cKDTree(flat, boxsize=L).query_pairs(min_contact, output_type="ndarray")
+        bad = pairs[(pairs[:, 0] // 3) != (pairs[:, 1] // 3)]
+        if len(bad) == 0:
+            break
+        redo = np.unique(bad[:, 1] // 3)
+        pos[redo] = place(random_rotations(len(redo)), centres[redo])
     lo, hi = np.full(3, -L / 2), np.full(3, L / 2)
-    x = lo + np.mod(x - lo, L)
+    x = lo + np.mod(pos.reshape(-1, 3), L)
+    x[x >= hi] = lo[0]
+    types = np.tile(np.array([type_O, type_H, type_H], dtype=np.int32), nmol)
     return System(x, types, lo, hi)
 
 
