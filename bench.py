@@ -84,7 +84,7 @@ def main():
     model = mf.synthetic_model("ani2x", args.models, seed=2024)
     mpath = f"/tmp/bench_ani2x_m{args.models}_r{rank}.anim"
     mf.write_model(mpath, model)
-    system = hx.water_box(args.atoms, seed=12345)
+    system = hx.spatial_sort(hx.water_box(args.atoms, seed=12345))  # LAMMPS sorts atoms spatially (atom_modify sort)
     grid = comm.grid_for(world)
     inp = hx.decompose(system, grid, rank, cutoff=5.1, skin=2.0)
     ani = ani_hip.ANI(mpath, local_rank, -1, use_cuaev=(args.aev == "cuaev"), use_fullnbr=True, use_single=True)

@@ -14,7 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_CSRC, "libani_hip.so")
+# ANI_HIP_LIB selects an alternative build of the same library (kernel A/B experiments); never a different backend
+LIB_PATH = os.environ.get("ANI_HIP_LIB") or os.path.join(_CSRC, "libani_hip.so")
 HARTREE2KCALMOL = 627.5094738898777
 
 EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani_use_num_models", "ani_num_species",

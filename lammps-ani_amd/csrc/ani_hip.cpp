@@ -80,6 +80,7 @@ struct ani_handle {
   int max_numneigh = 0;
   DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
   DevBuf<float4> xyzs;
+  DevBuf<int4> row_info;
   DevBuf<double> x64, f64, ev, eatom, partial, virial_acc;
   DevBuf<float> aev, gaev, act, e_rows, fbuf;
   std::vector<std::vector<float*>> Hbuf, Gbuf;  // [S][k] pointers into act
@@ -190,8 +191,9 @@ int rebuild(ani_handle* h, hipStream_t st) {
   HIP_TRY(h, h->nbr_off.reserve((size_t)nlocal + 1));
   HIP_TRY(h, h->row_of_centre.reserve((size_t)2 * nlocal + 2));
   HIP_TRY(h, h->centre_of_row.reserve(nrows_cap));
+  HIP_TRY(h, h->row_info.reserve(nrows_cap));
   HIP_TRY(h, h->bucket_info.reserve(kBucketInfoInts));
-  PrepOut o{h->nbr_off.p, h->row_of_centre.p, h->centre_of_row.p, h->bucket_info.p};
+  PrepOut o{h->nbr_off.p, h->row_of_centre.p, h->centre_of_row.p, h->row_info.p, h->bucket_info.p};
   launch_prepare(h->species.p, h->ilist.p, h->numneigh.p, nlocal, h->ntotal, m.S, nrows_cap, o, st);
   int info[kBucketInfoInts];
   HIP_TRY(h, hipMemcpyAsync(info, h->bucket_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
@@ -316,7 +318,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
 
   AevArgs a{};
   a.xyzs = h->xyzs.p; a.ilist = h->ilist.p; a.numneigh = h->numneigh.p; a.nbr_off = h->nbr_off.p; a.jlist = h->jlist.p;
-  a.centre_of_row = h->centre_of_row.p; a.nrows = h->nrows; a.aev = h->aev.p; a.gaev = h->gaev.p; a.fbuf = h->fbuf.p;
+  a.centre_of_row = h->centre_of_row.p; a.row_info = h->row_info.p; a.nrows = h->nrows; a.aev = h->aev.p; a.gaev = h->gaev.p; a.fbuf = h->fbuf.p;
   a.virial = vflag ? h->virial_acc.p : nullptr;
   a.err_flag = h->err_flag.p;
   launch_aev_forward(h->ap, a, h->max_numneigh, st);
@@ -428,7 +430,7 @@ void ani_destroy(ani_handle* h) {
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
   h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
-  h->xyzs.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release();
+  h->xyzs.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->e_rows.release(); h->fbuf.release();
   for (auto& e : h->evt_pool) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);

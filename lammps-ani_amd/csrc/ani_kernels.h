@@ -44,6 +44,7 @@ struct PrepOut {
   int* nbr_off;         // [nlocal+1] exclusive scan of numneigh
   int* row_of_centre;   // [nlocal]
   int* centre_of_row;   // [nrows_cap] (-1 = padding)
+  int4* row_info;       // [nrows_cap] per AEV row: {i, list begin, list length, ii}; i = -1 for padding rows
   int* bucket_info;     // [kBucketInfoInts]: count[s], row_start[s], nrows, bad_species flag, max numneigh
 };
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
@@ -56,6 +57,7 @@ struct AevArgs {
   const int* nbr_off;
   const int* jlist;
   const int* centre_of_row;
+  const int4* row_info;  // [nrows] {centre atom i (-1: padding row), first list slot, list length, centre position ii}
   int nrows;
   float* aev;        // [nrows][aev_stride]
   const float* gaev; // backward only

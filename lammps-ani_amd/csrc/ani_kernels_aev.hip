@@ -28,7 +28,8 @@
 
 namespace ani {
 
-constexpr int kWaves = 4;
+constexpr int kWaves = 4;    // centres per workgroup: forward fast path and generic kernels
+constexpr int kWavesB = 2;   // backward fast path (its per-wave LDS slice is larger)
 constexpr int kAevMax = 1024;   // LDS floats reserved for one AEV row (ANI-2x: 1008)
 constexpr int kMaxBuckets = 36; // species pairs on the fast path (S <= 8)
 
@@ -118,8 +119,10 @@ struct FastLds {
 };
 
 __host__ __device__ constexpr int fast_wave_floats(int cap, bool bwd) {
-  // ad 4*kMaxAng + afc kMaxAng + aidx kMaxAng + row kAevMax + pf 64*12 + tb kMaxBuckets*8 + pb 16 + starts 2*(kMaxSpecies+1)(->48)
-  return 6 * kMaxAng + kAevMax + 64 * 12 + kMaxBuckets * 8 + 16 + 48 + (bwd ? 9 * cap : 2 * cap);
+  // ad 4*kMaxAng + afc kMaxAng + aidx kMaxAng + row kAevMax + tb kMaxBuckets*8 + pb 16 + starts 2*24
+  // forward adds the phase-1 factor buffers pf (64*12) and r, fc per radial neighbour;
+  // backward adds r, fc, dx, dy, dz, j, gd[3] per radial neighbour
+  return 6 * kMaxAng + kAevMax + kMaxBuckets * 8 + 16 + 48 + (bwd ? 9 * cap : 64 * 12 + 2 * cap);
 }
 
 template <int NA, int NZ>
@@ -128,8 +131,12 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd) {
   float* p = base;
   L.ad = reinterpret_cast<float4*>(p); p += 4 * kMaxAng;
   L.row = p; p += kAevMax;
-  L.pf2 = p; p += 64 * NA;
-  L.pf1 = p; p += 64 * NZ;
+  if (!bwd) {
+    L.pf2 = p; p += 64 * NA;
+    L.pf1 = p; p += 64 * NZ;
+  } else {
+    L.pf2 = L.pf1 = nullptr;
+  }
   L.tb = reinterpret_cast<int*>(p); p += kMaxBuckets * 8;
   L.afc = p; p += kMaxAng;
   L.aidx = reinterpret_cast<int*>(p); p += kMaxAng;
@@ -153,51 +160,68 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd) {
 
 // Screen + compact the (species-sorted) neighbours of centre ii.  Lane s (< S) leaves with the number of radial /
 // angular neighbours of species s in cr / ca; group starts are written to L.rstart / L.astart.
+// info = row_info[row] = {centre atom i, first list slot, list length, centre position ii}.
+// The list is walked in super-chunks of 4 x 64 candidates: all jlist loads of a super-chunk are issued first, then
+// all position gathers, so a typical ~150-neighbour centre costs two dependent memory round trips, not six.
 template <bool BWD>
-__device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs& a, int ii, int lane, int cap, FastLds& L,
+__device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs& a, const int4 info, int lane, int cap, FastLds& L,
                                                int& nrad, int& nang, bool& over) {
-  const int i = a.ilist[ii];
+  const int i = info.x;
+  const int beg = info.y;
+  const int n = info.z;
   const float4 xi = a.xyzs[i];
-  const int beg = a.nbr_off[ii];
-  const int n = a.numneigh[ii];
   nrad = 0;
   nang = 0;
   over = false;
   int cr = 0, ca = 0;  // lane s: count of species s
   const float half_inv_Rcr = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;  // r/(2 Rcr) revolutions
   const float half_inv_Rca = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
-  for (int base = 0; base < n; base += 64) {
-    const int q = base + lane;
-    const bool valid = q < n;
-    const int j = valid ? a.jlist[beg + q] : i;
-    const float4 xj = a.xyzs[j];
-    const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
-    const float r2 = dx * dx + dy * dy + dz * dz;
-    const float r = __builtin_amdgcn_sqrtf(r2);
-    const int sp = __float_as_int(xj.w);
-    const bool in_r = valid && (p.compat || r <= p.Rcr);
-    const bool in_a = valid && r <= p.Rca;
-    const unsigned long long mr = __ballot(in_r);
-    const unsigned long long ma = __ballot(in_a);
-    const int pos = nrad + lanes_below(mr);
-    if (in_r && pos < cap) {
-      L.rr[pos] = r;
-      L.rfc[pos] = 0.5f * fcos_rev(r * half_inv_Rcr) + 0.5f;
-      if (BWD) { L.rdx[pos] = dx; L.rdy[pos] = dy; L.rdz[pos] = dz; L.rj[pos] = j; }
+  for (int base0 = 0; base0 < n; base0 += 256) {
+    int jj[4];
+    float4 xx[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int q = base0 + 64 * c + lane;
+      jj[c] = q < n ? a.jlist[beg + q] : i;
     }
-    const int posa = nang + lanes_below(ma);
-    if (in_a && posa < kMaxAng) {
-      L.ad[posa] = make_float4(dx, dy, dz, r);
-      L.afc[posa] = 0.5f * fcos_rev(r * half_inv_Rca) + 0.5f;
-      if (BWD) L.aidx[posa] = pos;
+#pragma unroll
+    for (int c = 0; c < 4; c++) xx[c] = a.xyzs[jj[c]];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int base = base0 + 64 * c;
+      if (base < n) {  // wave-uniform
+        const bool valid = base + lane < n;
+        const int j = jj[c];
+        const float4 xj = xx[c];
+        const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
+        const float r2 = dx * dx + dy * dy + dz * dz;
+        const float r = __builtin_amdgcn_sqrtf(r2);
+        const int sp = __float_as_int(xj.w);
+        const bool in_r = valid && (p.compat || r <= p.Rcr);
+        const bool in_a = valid && r <= p.Rca;
+        const unsigned long long mr = __ballot(in_r);
+        const unsigned long long ma = __ballot(in_a);
+        const int pos = nrad + lanes_below(mr);
+        if (in_r && pos < cap) {
+          L.rr[pos] = r;
+          L.rfc[pos] = 0.5f * fcos_rev(r * half_inv_Rcr) + 0.5f;
+          if (BWD) { L.rdx[pos] = dx; L.rdy[pos] = dy; L.rdz[pos] = dz; L.rj[pos] = j; }
+        }
+        const int posa = nang + lanes_below(ma);
+        if (in_a && posa < kMaxAng) {
+          L.ad[posa] = make_float4(dx, dy, dz, r);
+          L.afc[posa] = 0.5f * fcos_rev(r * half_inv_Rca) + 0.5f;
+          if (BWD) L.aidx[posa] = pos;
+        }
+        for (int s = 0; s < p.S; s++) {
+          const int c1 = __popcll(__ballot(in_r && sp == s));
+          const int c2 = __popcll(__ballot(in_a && sp == s));
+          if (lane == s) { cr += c1; ca += c2; }
+        }
+        nrad += __popcll(mr);
+        nang += __popcll(ma);
+      }
     }
-    for (int s = 0; s < p.S; s++) {
-      const int c1 = __popcll(__ballot(in_r && sp == s));
-      const int c2 = __popcll(__ballot(in_a && sp == s));
-      if (lane == s) { cr += c1; ca += c2; }
-    }
-    nrad += __popcll(mr);
-    nang += __popcll(ma);
   }
   if (nrad > cap) { nrad = cap; over = true; }
   if (nang > kMaxAng) { nang = kMaxAng; over = true; }
@@ -280,14 +304,14 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, Aev
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * kWaves + wave;
   if (row >= a.nrows) return;
-  const int ii = a.centre_of_row[row];
-  if (ii < 0) return;  // bucket padding: row stays zero (cleared at rebuild)
+  const int4 info = a.row_info[row];
+  if (info.x < 0) return;  // bucket padding: row stays zero (cleared at rebuild)
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, false), cap, false);
 
   for (int e = lane; e < kAevMax / 4; e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
   int nrad, nang;
   bool over;
-  compact_sorted<false>(p, a, ii, lane, cap, L, nrad, nang, over);
+  compact_sorted<false>(p, a, info, lane, cap, L, nrad, nang, over);
   if (over && lane == 0) atomicOr(a.err_flag, 1);
   wave_sync();
 
@@ -385,14 +409,14 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, Aev
 }
 
 template <int NA, int NZ>
-__global__ __launch_bounds__(64 * kWaves) void aev_backward_fast(AevParams p, AevArgs a, int cap) {
+__global__ __launch_bounds__(64 * kWavesB) void aev_backward_fast(AevParams p, AevArgs a, int cap) {
   extern __shared__ float4 smem4[];
   constexpr int NR = 16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * kWaves + wave;
+  const int row = blockIdx.x * kWavesB + wave;
   if (row >= a.nrows) return;
-  const int ii = a.centre_of_row[row];
-  if (ii < 0) return;
+  const int4 info = a.row_info[row];
+  if (info.x < 0) return;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, true), cap, true);
 
   {
@@ -402,32 +426,31 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_fast(AevParams p, Ae
   }
   int nrad, nang;
   bool over;
-  compact_sorted<true>(p, a, ii, lane, cap, L, nrad, nang, over);
+  compact_sorted<true>(p, a, info, lane, cap, L, nrad, nang, over);
   if (over && lane == 0) atomicOr(a.err_flag, 1);
   wave_sync();
 
-  // ---- radial: one lane per neighbour ----
+  // ---- radial: one lane per neighbour (species from the group boundaries) ----
   {
     const float cR = -p.EtaR * kLog2e;
     const float rev = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;
-    for (int s = 0; s < p.S; s++) {
-      const int b0 = L.rstart[s], b1 = L.rstart[s + 1];
+    for (int t = lane; t < nrad; t += 64) {
+      int s = 0;
+      for (int k = 1; k < p.S; k++) s += (t >= L.rstart[k]) ? 1 : 0;
       const float* gg = L.row + s * NR;
-      for (int t = b0 + lane; t < b1; t += 64) {
-        const float r = L.rr[t], fc = L.rfc[t];
-        const float dfc = -0.5f * p.pi_over_Rcr * fsin_rev(r * rev);
-        float dEdr = 0.f;
+      const float r = L.rr[t], fc = L.rfc[t];
+      const float dfc = -0.5f * p.pi_over_Rcr * fsin_rev(r * rev);
+      float dEdr = 0.f;
 #pragma unroll
-        for (int k = 0; k < NR; k++) {
-          const float dr = r - p.ShfR[k];
-          const float e = fexp2(cR * dr * dr);
-          dEdr = fmaf(gg[k] * e, fmaf(-2.f * p.EtaR * dr, fc, dfc), dEdr);
-        }
-        const float sc = 0.25f * dEdr * frcp(r);
-        L.gd[3 * t + 0] = sc * L.rdx[t];
-        L.gd[3 * t + 1] = sc * L.rdy[t];
-        L.gd[3 * t + 2] = sc * L.rdz[t];
+      for (int k = 0; k < NR; k++) {
+        const float dr = r - p.ShfR[k];
+        const float e = fexp2(cR * dr * dr);
+        dEdr = fmaf(gg[k] * e, fmaf(-2.f * p.EtaR * dr, fc, dfc), dEdr);
       }
+      const float sc = 0.25f * dEdr * frcp(r);
+      L.gd[3 * t + 0] = sc * L.rdx[t];
+      L.gd[3 * t + 1] = sc * L.rdy[t];
+      L.gd[3 * t + 2] = sc * L.rdz[t];
     }
   }
   int nbk;
@@ -437,7 +460,11 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_fast(AevParams p, Ae
   // ---- angular: lane = pair of the padded stream ----
   const float cA = -p.EtaA * kLog2e;
   const float revA = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
+#ifdef ABL_NO_ANG
+  for (int base = 0; base < 0; base += 64) {
+#else
   for (int base = 0; base < total; base += 64) {
+#endif
     int ia, ib, outoff;
     bool valid;
     stream_pair(L, nbk, base + lane, ia, ib, outoff, valid);
@@ -479,7 +506,12 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_fast(AevParams p, Ae
       Cq = fmaf(f2, g1, Cq);
       Bq = fmaf(df2, g1, Bq);
     }
+#ifdef ABL_NO_LATOM
+    asm volatile("" ::"v"(Aq), "v"(Bq), "v"(Cq));
+    if (false) {
+#else
     if (valid) {
+#endif
       const float P = fa * fb;
       Aq *= 2.f * P * 0.95f;
       Bq *= P;       // 2 * P * 0.5
@@ -504,9 +536,13 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_fast(AevParams p, Ae
   for (int q = lane; q < nrad; q += 64) {
     const float gx = L.gd[3 * q], gy = L.gd[3 * q + 1], gz = L.gd[3 * q + 2];
     const int j = L.rj[q];
+#ifdef ABL_NO_GATOM
+    asm volatile("" ::"v"(j));
+#else
     atomicAdd(&a.fbuf[3 * j + 0], -gx);
     atomicAdd(&a.fbuf[3 * j + 1], -gy);
     atomicAdd(&a.fbuf[3 * j + 2], -gz);
+#endif
     fx += gx; fy += gy; fz += gz;
     if (a.virial) {
       const float dx = L.rdx[q], dy = L.rdy[q], dz = L.rdz[q];
@@ -521,7 +557,7 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_fast(AevParams p, Ae
     fy += __shfl_xor(fy, off);
     fz += __shfl_xor(fz, off);
   }
-  const int i = a.ilist[ii];
+  const int i = info.x;
   if (lane == 0) {
     atomicAdd(&a.fbuf[3 * i + 0], fx);
     atomicAdd(&a.fbuf[3 * i + 1], fy);
@@ -777,8 +813,9 @@ static int fast_kind(const AevParams& p) {
 bool aev_fast_path(const AevParams& p, int max_numneigh) {
   if (!fast_kind(p)) return false;
   const int cap = (max_numneigh + 63) / 64 * 64;
-  // one wave's slice of the backward kernel must fit in 160 KB / kWaves
-  return (size_t)fast_wave_floats(cap < 64 ? 64 : cap, true) * 4 * kWaves <= 160 * 1024;
+  // a backward workgroup (kWavesB slices) and a forward workgroup (kWaves slices) must each fit in 160 KB
+  const int c = cap < 64 ? 64 : cap;
+  return (size_t)fast_wave_floats(c, true) * 4 * kWavesB <= 160 * 1024 && (size_t)fast_wave_floats(c, false) * 4 * kWaves <= 160 * 1024;
 }
 
 void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
@@ -805,18 +842,19 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
 void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
   if (a.nrows <= 0) return;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
+  const dim3 gridB((a.nrows + kWavesB - 1) / kWavesB), blockB(64 * kWavesB);
   if (aev_fast_path(p, max_numneigh)) {
     int cap = (max_numneigh + 63) / 64 * 64;
     if (cap < 64) cap = 64;
-    const size_t lds = (size_t)fast_wave_floats(cap, true) * 4 * kWaves;
+    const size_t lds = (size_t)fast_wave_floats(cap, true) * 4 * kWavesB;
     if (fast_kind(p) == 1) {
       static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_backward_fast<8, 4>), grid, block, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_backward_fast<8, 4>), gridB, blockB, lds, st, p, a, cap);
     } else {
       static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_backward_fast<4, 8>), grid, block, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_backward_fast<4, 8>), gridB, blockB, lds, st, p, a, cap);
     }
   } else {
     hipLaunchKernelGGL(aev_backward_generic, grid, block, 0, st, p, a);

@@ -110,7 +110,10 @@ __global__ void prepare_rows_kernel(const int* __restrict__ species, const int* 
   if (sp < 0 || sp >= S) { o.row_of_centre[ii] = -1; return; }
   const int row = row_start[sp] + rank_in_species[ii];
   o.row_of_centre[ii] = row;
-  if (row < nrows_cap) o.centre_of_row[row] = ii;
+  if (row < nrows_cap) {
+    o.centre_of_row[row] = ii;
+    o.row_info[row] = make_int4(ilist[ii], o.nbr_off[ii], o.nbr_off[ii + 1] - o.nbr_off[ii], ii);
+  }
 }
 
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
@@ -118,6 +121,7 @@ void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numne
   // row_of_centre is sized 2*nlocal by the caller: the second half is the rank-in-species scratch
   int* rank = o.row_of_centre + nlocal;
   (void)hipMemsetAsync(o.centre_of_row, 0xff, sizeof(int) * (size_t)nrows_cap, st);
+  (void)hipMemsetAsync(o.row_info, 0xff, sizeof(int4) * (size_t)nrows_cap, st);
   (void)hipMemsetAsync(o.bucket_info, 0, sizeof(int) * kBucketInfoInts, st);
   hipLaunchKernelGGL(prepare_count_kernel, dim3(S + 2), dim3(1024), 0, st, d_species, d_ilist, d_numneigh, nlocal, ntotal, S, o, rank);
   if (nlocal > 0)
