@@ -1,0 +1,290 @@
+/* ----------------------------------------------------------------------
+   pair_style ani — LAMMPS host adapter over libani_hip.so (see pair_ani.h).
+
+   What this file has to reproduce from the reference adapter (src/pair_ani.cpp), and where it deliberately differs:
+     - units real only, comm_reverse(_off) = 3, single_enable = 0                      (ref :36-51)
+     - settings grammar and defaults                                                    (ref :285-341)
+     - pair_coeff * * only                                                              (ref :347-368)
+     - newton_pair must be off for both list kinds; REQ_FULL or default half request    (ref :374-390)
+     - per step: x, type-1 and the neighbour list go to the model; forces for local AND ghost atoms come back into
+       out_force, ghosts are summed to their owners with reverse_comm(this) when newton is off, then f += out_force
+       for all ntotal atoms; eng_vdwl, eatom, virial[6] = xx yy zz xy xz yz            (ref :66-233)
+     - restart record layout                                                            (ref :408-455)
+   Differences: atom->x is handed over in place (it is one contiguous ntotal*3 block) instead of being copied;
+   numneigh is gathered THROUGH ilist (the reference sums numneigh[ii] but walks firstneigh[ilist[ii]], which
+   only agrees when ilist is the identity, SURVEY.md section 7 "numneigh indexing wart"); eatom is scattered through
+   ilist; device "cpu" is refused (no host arithmetic in this build); "hip" is accepted next to "cuda".
+------------------------------------------------------------------------- */
+
+#include "pair_ani.h"
+
+#include <mpi.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "atom.h"
+#include "comm.h"
+#include "error.h"
+#include "force.h"
+#include "memory.h"
+#include "neigh_list.h"
+#include "neighbor.h"
+#include "update.h"
+
+using namespace LAMMPS_NS;
+
+PairANI::PairANI(LAMMPS* lmp) : Pair(lmp) {
+  writedata = 0;
+  single_enable = 0;
+  restartinfo = 1;
+  if (strcmp(update->unit_style, "real") != 0) error->all(FLERR, "Pair ani requires real units");
+  comm_reverse = 3;
+  comm_reverse_off = 3;
+  const char* prof = getenv("LAMMPS_ANI_PROFILING");
+  profiling = prof && *prof && strcmp(prof, "0") != 0;
+}
+
+PairANI::~PairANI() {
+  if (allocated) {
+    memory->destroy(setflag);
+    memory->destroy(cutsq);
+  }
+  if (ani) ani_destroy(ani);
+}
+
+void PairANI::allocate() {
+  allocated = 1;
+  const int n = atom->ntypes;
+  memory->create(setflag, n + 1, n + 1, "pair:setflag");
+  for (int i = 1; i <= n; i++)
+    for (int j = i; j <= n; j++) setflag[i][j] = 0;
+  memory->create(cutsq, n + 1, n + 1, "pair:cutsq");
+}
+
+/* node-local rank -> device ordinal (the library takes it modulo the visible device count) */
+int PairANI::node_local_rank() {
+  int rank = 0, local = 0;
+  MPI_Comm_rank(world, &rank);
+  MPI_Comm node;
+  MPI_Comm_split_type(world, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node);
+  MPI_Comm_rank(node, &local);
+  MPI_Comm_free(&node);
+  return local;
+}
+
+void PairANI::create_model() {
+  if (device_str == "cpu")
+    error->all(FLERR, "Pair ani: device 'cpu' is not available in the MI355X build (use 'hip' or 'cuda')");
+  if (device_str != "hip" && device_str != "cuda") error->all(FLERR, "Pair ani: device must be hip (or cuda)");
+  if (ani) {
+    ani_destroy(ani);
+    ani = nullptr;
+  }
+  const int rc = ani_create(model_file.c_str(), node_local_rank(), use_num_models, use_cuaev ? 1 : 0, use_fullnbr ? 1 : 0,
+                            use_single ? 1 : 0, &ani);
+  if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(nullptr));
+}
+
+/* pair_style ani cutoff model_file device [num_models] [cuaev|pyaev] [full|half] [single|double] */
+void PairANI::settings(int narg, char** arg) {
+  if (narg < 3) error->all(FLERR, "Illegal pair_style command");
+  cutoff = utils::numeric(FLERR, arg[0], false, lmp);
+  model_file = arg[1];
+  device_str = arg[2];
+  use_num_models = narg > 3 ? utils::inumeric(FLERR, arg[3], false, lmp) : -1;
+  use_cuaev = true;
+  use_fullnbr = true;
+  use_single = true;
+  if (narg > 4) {
+    if (strcmp(arg[4], "cuaev") == 0) use_cuaev = true;
+    else if (strcmp(arg[4], "pyaev") == 0) use_cuaev = false;
+    else error->all(FLERR, "ani_aev should be cuaev or pyaev");
+  }
+  if (narg > 5) {
+    if (strcmp(arg[5], "full") == 0) use_fullnbr = true;
+    else if (strcmp(arg[5], "half") == 0) use_fullnbr = false;
+    else error->all(FLERR, "ani_neighbor should be full or half");
+  }
+  if (narg > 6) {
+    if (strcmp(arg[6], "single") == 0) use_single = true;
+    else if (strcmp(arg[6], "double") == 0) use_single = false;
+    else error->all(FLERR, "precision should be single or double");
+  }
+  create_model();
+}
+
+void PairANI::coeff(int narg, char** arg) {
+  if (!allocated) allocate();
+  if (narg != 2) error->all(FLERR, "Incorrect args for pair coefficients, it should be set as: pair_coeff * *");
+  int ilo, ihi, jlo, jhi;
+  const int n = atom->ntypes;
+  utils::bounds(FLERR, arg[0], 1, n, ilo, ihi, error);
+  utils::bounds(FLERR, arg[1], 1, n, jlo, jhi, error);
+  if (ilo != 1 || jlo != 1 || ihi != n || jhi != n)
+    error->all(FLERR, "Incorrect args for pair coefficients, it should be set as: pair_coeff * *");
+  for (int i = ilo; i <= ihi; i++)
+    for (int j = (jlo > i ? jlo : i); j <= jhi; j++) setflag[i][j] = 1;
+}
+
+void PairANI::init_style() {
+  if (!ani) error->all(FLERR, "Pair ani: no model loaded");
+  if (force->newton_pair == 1) {
+    if (use_fullnbr) error->all(FLERR, "Pair style ANI requires newton pair off when using full neighbor list");
+    error->all(FLERR, "Pair style ANI requires newton pair off when using half neighbor list");
+  }
+  if (use_fullnbr)
+    neighbor->add_request(this, NeighConst::REQ_FULL);
+  else
+    neighbor->add_request(this);
+}
+
+double PairANI::init_one(int, int) { return cutoff; }
+
+void* PairANI::extract(const char*, int&) { return nullptr; }
+
+void PairANI::compute(int eflag, int vflag) {
+  ev_init(eflag, vflag);
+
+  double** x = atom->x;
+  double** f = atom->f;
+  const int* type = atom->type;
+  const int nlocal = atom->nlocal;
+  const int ntotal = nlocal + atom->nghost;
+  const int ago = neighbor->ago;
+  const int inum = list->inum;
+
+  if (ago == 0) {
+    species.resize(ntotal);
+    for (int i = 0; i < ntotal; i++) species[i] = type[i] - 1;
+    const int* ilist = list->ilist;
+    const int* numneigh = list->numneigh;
+    int** firstneigh = list->firstneigh;
+    npairs = 0;
+    for (int ii = 0; ii < inum; ii++) npairs += numneigh[ilist[ii]];
+    if (use_fullnbr) {
+      if ((int64_t)flat_jlist.capacity() < npairs) flat_jlist.reserve((size_t)(npairs * 1.5));
+      flat_jlist.resize(npairs);
+      flat_ilist.resize(inum);
+      flat_numneigh.resize(inum);
+      int64_t p = 0;
+      for (int ii = 0; ii < inum; ii++) {
+        const int i = ilist[ii];
+        const int jnum = numneigh[i];
+        const int* jl = firstneigh[i];
+        flat_ilist[ii] = i;
+        flat_numneigh[ii] = jnum;
+        for (int jj = 0; jj < jnum; jj++) flat_jlist[p++] = jl[jj] & NEIGHMASK;
+      }
+    } else {
+      if ((int64_t)atom_index12.capacity() < 2 * npairs) atom_index12.reserve((size_t)(2 * npairs * 1.5));
+      atom_index12.resize(2 * npairs);
+      int64_t p = 0;
+      for (int ii = 0; ii < inum; ii++) {
+        const int i = ilist[ii];
+        const int jnum = numneigh[i];
+        const int* jl = firstneigh[i];
+        for (int jj = 0; jj < jnum; jj++) {
+          atom_index12[p] = i;
+          atom_index12[npairs + p] = jl[jj] & NEIGHMASK;
+          p++;
+        }
+      }
+    }
+  }
+
+  out_force.resize((size_t)ntotal * 3);
+  if (eflag_atom) out_eatom.resize(use_fullnbr ? inum : nlocal);
+  double out_energy = 0.0;
+  double out_virial[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const double* coords = ntotal > 0 ? &x[0][0] : nullptr;
+  static const double dummy[3] = {0, 0, 0};
+  if (!coords) coords = dummy;
+
+  int rc;
+  if (use_fullnbr) {
+    if (inum != nlocal) error->one(FLERR, "Pair ani: full neighbor list does not cover every local atom");
+    rc = ani_compute_full(ani, ntotal, nlocal, species.data(), coords, npairs, flat_ilist.data(), flat_jlist.data(),
+                          flat_numneigh.data(), ago, eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, out_force.data(),
+                          eflag_atom ? out_eatom.data() : nullptr, out_virial);
+  } else {
+    rc = ani_compute_half(ani, ntotal, nlocal, species.data(), coords, npairs, atom_index12.data(), ago, eflag_atom ? 1 : 0,
+                          vflag_either ? 1 : 0, &out_energy, out_force.data(), eflag_atom ? out_eatom.data() : nullptr, out_virial);
+  }
+  if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(ani));
+
+  // ghost forces go home from out_force (f's ghost entries are not cleared between steps when newton is off)
+  if (!force->newton) comm->reverse_comm(this);
+
+  for (int i = 0; i < ntotal; i++) {
+    f[i][0] += out_force[3 * i + 0];
+    f[i][1] += out_force[3 * i + 1];
+    f[i][2] += out_force[3 * i + 2];
+  }
+  if (eflag_global) eng_vdwl += out_energy;
+  if (eflag_atom) {
+    if (use_fullnbr)
+      for (int ii = 0; ii < inum; ii++) eatom[flat_ilist[ii]] += out_eatom[ii];
+    else
+      for (int i = 0; i < nlocal; i++) eatom[i] += out_eatom[i];
+  }
+  if (vflag_either) {
+    virial[0] += out_virial[0];
+    virial[1] += out_virial[4];
+    virial[2] += out_virial[8];
+    virial[3] += out_virial[1];
+    virial[4] += out_virial[2];
+    virial[5] += out_virial[5];
+  }
+}
+
+/* restart record, byte-compatible with the reference (src/pair_ani.cpp:435-455):
+   double cutoff; int use_num_models; bool use_cuaev, use_fullnbr, use_single; int len_model, len_device; chars */
+void PairANI::write_restart(FILE* fp) {
+  fwrite(&cutoff, sizeof(double), 1, fp);
+  fwrite(&use_num_models, sizeof(int), 1, fp);
+  fwrite(&use_cuaev, sizeof(bool), 1, fp);
+  fwrite(&use_fullnbr, sizeof(bool), 1, fp);
+  fwrite(&use_single, sizeof(bool), 1, fp);
+  const int n1 = (int)model_file.size(), n2 = (int)device_str.size();
+  fwrite(&n1, sizeof(int), 1, fp);
+  fwrite(&n2, sizeof(int), 1, fp);
+  fwrite(model_file.c_str(), sizeof(char), n1, fp);
+  fwrite(device_str.c_str(), sizeof(char), n2, fp);
+}
+
+void PairANI::read_restart(FILE* fp) {
+  int n1 = 0, n2 = 0;
+  utils::sfread(FLERR, &cutoff, sizeof(double), 1, fp, nullptr, error);
+  utils::sfread(FLERR, &use_num_models, sizeof(int), 1, fp, nullptr, error);
+  utils::sfread(FLERR, &use_cuaev, sizeof(bool), 1, fp, nullptr, error);
+  utils::sfread(FLERR, &use_fullnbr, sizeof(bool), 1, fp, nullptr, error);
+  utils::sfread(FLERR, &use_single, sizeof(bool), 1, fp, nullptr, error);
+  utils::sfread(FLERR, &n1, sizeof(int), 1, fp, nullptr, error);
+  utils::sfread(FLERR, &n2, sizeof(int), 1, fp, nullptr, error);
+  model_file.resize(n1);
+  device_str.resize(n2);
+  utils::sfread(FLERR, &model_file[0], sizeof(char), n1, fp, nullptr, error);
+  utils::sfread(FLERR, &device_str[0], sizeof(char), n2, fp, nullptr, error);
+  create_model();
+}
+
+int PairANI::pack_reverse_comm(int n, int first, double* buf) {
+  int m = 0;
+  for (int i = first; i < first + n; i++) {
+    buf[m++] = out_force[3 * i + 0];
+    buf[m++] = out_force[3 * i + 1];
+    buf[m++] = out_force[3 * i + 2];
+  }
+  return m;
+}
+
+void PairANI::unpack_reverse_comm(int n, int* list, double* buf) {
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const int j = list[i];
+    out_force[3 * j + 0] += buf[m++];
+    out_force[3 * j + 1] += buf[m++];
+    out_force[3 * j + 2] += buf[m++];
+  }
+}

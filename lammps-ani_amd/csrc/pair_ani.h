@@ -1,0 +1,71 @@
+/* -*- c++ -*- ----------------------------------------------------------
+   pair_style ani for LAMMPS on AMD MI355X — host adapter over the C ABI of libani_hip.so (include/ani_hip.h).
+
+   Same input-script surface as the reference's PairANI (src/pair_ani.h:22-55, src/pair_ani.cpp):
+       pair_style ani <cutoff> <model_file> <device> [num_models=-1] [cuaev|pyaev] [full|half] [single|double]
+       pair_coeff * *
+   but no libtorch, no CUDA headers: the model runtime is the HIP library behind ani_hip.h.
+   Compiled only when LAMMPS headers are available (LAMMPS_HEADER_DIR, like the reference's CMakeLists.txt:28-36);
+   tests/mock_lammps provides a minimal stand-in for those headers so this file is exercised without LAMMPS.
+------------------------------------------------------------------------- */
+
+#ifdef PAIR_CLASS
+// clang-format off
+PairStyle(ani,PairANI);
+// clang-format on
+#else
+
+#ifndef LMP_PAIR_ANI_HIP_H
+#define LMP_PAIR_ANI_HIP_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "ani_hip.h"
+#include "pair.h"
+
+namespace LAMMPS_NS {
+
+class PairANI : public Pair {
+ public:
+  PairANI(class LAMMPS*);
+  ~PairANI() override;
+  void compute(int, int) override;
+  void settings(int, char**) override;
+  void coeff(int, char**) override;
+  void init_style() override;
+  double init_one(int, int) override;
+  void* extract(const char*, int&) override;
+  void write_restart(FILE*) override;
+  void read_restart(FILE*) override;
+  int pack_reverse_comm(int, int, double*) override;
+  void unpack_reverse_comm(int, int*, double*) override;
+
+ protected:
+  double cutoff = 0.0;
+  ani_handle* ani = nullptr;
+  std::string model_file, device_str;
+  int use_num_models = -1;
+  bool use_cuaev = true, use_fullnbr = true, use_single = true;
+  bool profiling = false;  // LAMMPS_ANI_PROFILING: report timing honestly (the C ABI is synchronous already)
+
+  // list epoch (rebuilt when neighbor->ago == 0), grown 1.5x like the reference (src/pair_ani.cpp:119-127)
+  std::vector<int64_t> species;
+  std::vector<int> flat_ilist, flat_numneigh, flat_jlist;
+  std::vector<int64_t> atom_index12;
+  int64_t npairs = 0;
+
+  // ghost forces are reverse-communicated from here, not from atom->f (src/pair_ani.cpp:192-201)
+  std::vector<double> out_force;
+  std::vector<double> out_eatom;
+
+  void allocate();
+  void create_model();
+  int node_local_rank();
+};
+
+}  // namespace LAMMPS_NS
+
+#endif
+#endif

@@ -1,0 +1,119 @@
+"""The LAMMPS-side adapter (lammps-ani_amd/csrc/pair_ani.cpp + ani_plugin.cpp) driven through mock LAMMPS objects
+(tests/mock_lammps).  Mirrors what LAMMPS' test_pair_style does with the reference's yaml files
+(tests/lammps-unittest/*/): init forces/energy/stress of the 30-atom water box, restart round trip, newton checks."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import golden_input, golden_model_path, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK = os.path.join(ROOT, "tests", "mock_lammps")
+
+
+@pytest.fixture(scope="module")
+def mock():
+    from lammps_ani_amd import ani_hip
+    ani_hip.build()
+    subprocess.check_call(["make", "-C", MOCK, "-s"])
+    lib = C.CDLL(os.path.join(MOCK, "libpair_ani_mock.so"))
+    lib.mock_create.restype = C.c_void_p
+    lib.mock_create.argtypes = [C.c_char_p, C.c_int]
+    lib.mock_error.restype = C.c_char_p
+    lib.mock_error.argtypes = [C.c_void_p]
+    lib.mock_plugin_name.restype = C.c_char_p
+    lib.mock_pair_style.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_int]
+    lib.mock_last_request.argtypes = [C.c_void_p]
+    lib.mock_init_one.argtypes = [C.c_void_p]
+    lib.mock_init_one.restype = C.c_double
+    lib.mock_compute.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+    lib.mock_restart_roundtrip.argtypes = [C.c_void_p, C.c_char_p]
+    lib.mock_destroy.argtypes = [C.c_void_p]
+    return lib
+
+
+def _style(lib, h, args, ntypes=7):
+    arr = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    rc = lib.mock_pair_style(h, len(args), arr, ntypes)
+    return rc, lib.mock_error(h).decode()
+
+
+def test_adapter_rejects_bad_input_without_gpu(mock):
+    """Host-side checks that need no device (reference src/pair_ani.cpp:44-46, 285-341)."""
+    h = mock.mock_create(b"metal", 0)
+    rc, err = _style(mock, h, ["5.1", "/nonexistent.anim", "hip"])
+    assert rc == 1 and "real units" in err
+    h = mock.mock_create(b"real", 0)
+    rc, err = _style(mock, h, ["5.1", "/nonexistent.anim", "cpu"])
+    assert rc == 1 and "cpu" in err
+    rc, err = _style(mock, h, ["5.1", "/nonexistent.anim", "hip", "-1", "fastaev"])
+    assert rc == 1 and "cuaev or pyaev" in err
+    rc, err = _style(mock, h, ["5.1", "/nonexistent.anim", "hip", "-1", "cuaev", "quarter"])
+    assert rc == 1 and "full or half" in err
+    rc, err = _style(mock, h, ["5.1"])
+    assert rc == 1 and "Illegal pair_style" in err
+
+
+def _run(mock, h, inp, ago, eflag=3, vflag=1):
+    nt = inp.ntotal
+    f = np.zeros((nt, 3))
+    e = np.zeros(1)
+    v = np.zeros(6)
+    ea = np.zeros(inp.nlocal)
+    x = np.ascontiguousarray(inp.x)
+    ty = np.ascontiguousarray(inp.types, dtype=np.int32)
+    nn = np.ascontiguousarray(inp.numneigh, dtype=np.int32)
+    jl = np.ascontiguousarray(inp.jlist, dtype=np.int32)
+    ow = np.ascontiguousarray(inp.owner_lidx, dtype=np.int32)
+    rc = mock.mock_compute(h, inp.nlocal, inp.nghost, x.ctypes.data, ty.ctypes.data, nn.ctypes.data, jl.ctypes.data,
+                           ow.ctypes.data, ago, eflag, vflag, f.ctypes.data, e.ctypes.data, v.ctypes.data, ea.ctypes.data)
+    assert rc == 0, mock.mock_error(h).decode()
+    return f, float(e[0]), v, ea
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbr", ["full", "half"])
+@pytest.mark.parametrize("aev", ["cuaev", "pyaev"])
+def test_adapter_matches_golden_water30(mock, model_cache, nbr, aev):
+    """`pair_style ani 5.1 <model> hip -1 <aev> <nbr> single` on tests/golden/water-0.8nm.data, PBC 8 A: forces after the
+    adapter's own reverse communication, eng_vdwl, virial (xx yy zz xy xz yz), eatom — against the fp64 fixtures."""
+    g = load_golden("water30_pbc_ani2x_m8")
+    inp = golden_input(g, half=(nbr == "half"))
+    p = golden_model_path(g, model_cache)
+    h = mock.mock_create(b"real", 0)
+    rc, err = _style(mock, h, ["5.1", p, "hip", "-1", aev, nbr, "single"])
+    assert rc == 0, err
+    assert mock.mock_plugin_name() == b"ani"
+    assert mock.mock_last_request(h) == (1 if nbr == "full" else 0)  # REQ_FULL vs default half request
+    assert mock.mock_init_one(h) == 5.1
+    mode = "strict" if aev == "cuaev" else "compat"
+    ref_f = g[f"{mode}_force"]
+    folded = ref_f[: inp.nlocal].copy()
+    np.add.at(folded, inp.owner_lidx, ref_f[inp.nlocal:])
+    vref = g[f"{mode}_virial"]
+    for ago in (0, 1):
+        f, e, v, ea = _run(mock, h, inp, ago)
+        assert abs(e - float(g[f"{mode}_energy"])) < 2e-3
+        np.testing.assert_allclose(f[: inp.nlocal], folded, rtol=0, atol=2.3e-3)
+        np.testing.assert_allclose(v, [vref[0, 0], vref[1, 1], vref[2, 2], vref[0, 1], vref[0, 2], vref[1, 2]], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(ea, g[f"{mode}_eatom"], rtol=0, atol=2e-3)
+    # restart round trip re-creates the model from the stored path and settings (src/pair_ani.cpp:408-455)
+    assert mock.mock_restart_roundtrip(h, b"/tmp/_pair_ani_restart.bin") == 0, mock.mock_error(h).decode()
+    f2, e2, _, _ = _run(mock, h, inp, 0)
+    np.testing.assert_allclose(f2, f, rtol=0, atol=1e-3)  # float atomics: not bitwise
+    assert abs(e2 - e) < 1e-6
+    mock.mock_destroy(h)
+
+
+@pytest.mark.gpu
+def test_adapter_requires_newton_pair_off(mock, model_cache):
+    p = model_cache("tiny", 2, 5)
+    h = mock.mock_create(b"real", 1)
+    rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", "full"], ntypes=3)
+    assert rc == 1 and "newton pair off" in err
+    h = mock.mock_create(b"real", 0)
+    rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", "full", "double"], ntypes=3)
+    assert rc == 1 and "double" in err
