@@ -231,7 +231,8 @@ int rebuild(ani_handle* h, hipStream_t st) {
   return ANI_OK;
 }
 
-// The MLP ensemble for every species bucket.  Buffers of species s are local to the bucket (row 0 = row_start[s]).
+// The MLP ensemble for every species bucket, one grouped launch per layer (all species and members together).
+// Buffers of species s are local to the bucket (row 0 = row_start[s]).
 //   W[k]  : [M][d[k+1]][w[k]]   Bt of forward layer k (K = w[k], zero padded)
 //   WT[k] : [M][d[k]][w[k+1]]   Bt of the backward product through layer k (k >= 1);  WT[0]: [aev_len][M*w[1]]
 //   H_k   : [rows][M*w[k]]      activations after layer k-1 (member a at column a*w[k]); overwritten by G_k = dE/dz_k
@@ -239,21 +240,28 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
   const HostModel& m = h->model;
   const int L = m.L, M = m.M;
   const float alpha = (float)m.alpha, inv_alpha = (float)(1.0 / m.alpha);
-  for (int s = 0; s < m.S; s++) {
-    if (h->count[s] == 0) continue;
-    const SpeciesNet& n = h->nets[s];
-    const std::vector<int>& d = m.dims[s];
-    const int rows = round_up(h->count[s], kRowTile);
-    const int r0 = h->row_start[s];
-    const float* aev = h->aev.p + (size_t)r0 * h->ap.aev_stride;
-    float* gaev = h->gaev.p + (size_t)r0 * h->ap.aev_stride;
-    const int* cor = h->centre_of_row.p + r0;
-    // forward
-    for (int k = 0; k <= L - 2; k++) {
-      GemmArgs g{};
-      g.rows = rows; g.row0 = 0; g.batch = M; g.alpha = alpha; g.inv_alpha = inv_alpha; g.scale = 1.f / (float)M;
-      g.centre_of_row = cor;
-      if (k == 0) { g.A = aev; g.lda = h->ap.aev_stride; g.sA = 0; }
+  std::vector<GemmArgs> probs;
+  probs.reserve(m.S);
+  auto base_args = [&](int s) {
+    GemmArgs g{};
+    g.rows = round_up(h->count[s], kRowTile);
+    g.row0 = 0;
+    g.batch = M;
+    g.alpha = alpha;
+    g.inv_alpha = inv_alpha;
+    g.scale = 1.f / (float)M;
+    g.centre_of_row = h->centre_of_row.p + h->row_start[s];
+    return g;
+  };
+  // forward
+  for (int k = 0; k <= L - 2; k++) {
+    probs.clear();
+    for (int s = 0; s < m.S; s++) {
+      if (h->count[s] == 0) continue;
+      const SpeciesNet& n = h->nets[s];
+      const std::vector<int>& d = m.dims[s];
+      GemmArgs g = base_args(s);
+      if (k == 0) { g.A = h->aev.p + (size_t)h->row_start[s] * h->ap.aev_stride; g.lda = h->ap.aev_stride; g.sA = 0; }
       else { g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k]; }
       g.K = n.w[k];
       g.Bt = n.W[k]; g.ldb = n.w[k]; g.sB = (long long)d[k + 1] * n.w[k];
@@ -263,33 +271,43 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
       if (k == L - 2) {
         g.aux = n.w_out; g.sAux = n.w[L - 1];
         g.bias_last = n.b_out;
-        g.e_out = h->e_rows.p + r0; g.sE = h->nrows;
-        launch_gemm(g, EPI_LAST, st);
-      } else {
-        launch_gemm(g, EPI_CELU, st);
+        g.e_out = h->e_rows.p + h->row_start[s]; g.sE = h->nrows;
       }
+      probs.push_back(g);
     }
-    // backward: G_{k-1} = (G_k W[k-1]) * celu'(z_{k-1}), in place over H_{k-1}
-    for (int k = L - 1; k >= 2; k--) {
-      GemmArgs g{};
-      g.rows = rows; g.row0 = 0; g.batch = M; g.alpha = alpha; g.inv_alpha = inv_alpha;
+    launch_gemm_group(probs.data(), (int)probs.size(), k == L - 2 ? EPI_LAST : EPI_CELU, st);
+  }
+  // backward: G_{k-1} = (G_k W[k-1]) * celu'(z_{k-1}), in place over H_{k-1}
+  for (int k = L - 1; k >= 2; k--) {
+    probs.clear();
+    for (int s = 0; s < m.S; s++) {
+      if (h->count[s] == 0) continue;
+      const SpeciesNet& n = h->nets[s];
+      const std::vector<int>& d = m.dims[s];
+      GemmArgs g = base_args(s);
       g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k]; g.K = n.w[k];
       g.Bt = n.WT[k - 1]; g.ldb = n.w[k]; g.sB = (long long)d[k - 1] * n.w[k];
       g.N = d[k - 1];
       g.aux = h->Hbuf[s][k - 1]; g.ldaux = M * n.w[k - 1]; g.sAux = n.w[k - 1];
       g.C = h->Hbuf[s][k - 1]; g.ldc = M * n.w[k - 1]; g.sC = n.w[k - 1];
-      launch_gemm(g, EPI_BWD, st);
+      probs.push_back(g);
     }
-    {  // dE/dAEV = sum over members of G_1 W[0]  (members concatenated along K)
-      GemmArgs g{};
-      g.rows = rows; g.row0 = 0; g.batch = 1;
-      g.A = h->Hbuf[s][1]; g.lda = M * n.w[1]; g.K = M * n.w[1];
-      g.Bt = n.WT[0]; g.ldb = M * n.w[1];
-      g.N = m.aev_len;
-      g.C = gaev; g.ldc = h->ap.aev_stride;
-      launch_gemm(g, EPI_PLAIN, st);
-    }
+    launch_gemm_group(probs.data(), (int)probs.size(), EPI_BWD, st);
   }
+  // dE/dAEV = sum over members of G_1 W[0]  (members concatenated along K)
+  probs.clear();
+  for (int s = 0; s < m.S; s++) {
+    if (h->count[s] == 0) continue;
+    const SpeciesNet& n = h->nets[s];
+    GemmArgs g = base_args(s);
+    g.batch = 1;
+    g.A = h->Hbuf[s][1]; g.lda = M * n.w[1]; g.K = M * n.w[1];
+    g.Bt = n.WT[0]; g.ldb = M * n.w[1];
+    g.N = m.aev_len;
+    g.C = h->gaev.p + (size_t)h->row_start[s] * h->ap.aev_stride; g.ldc = h->ap.aev_stride;
+    probs.push_back(g);
+  }
+  launch_gemm_group(probs.data(), (int)probs.size(), EPI_PLAIN, st);
 }
 
 // the per-step pipeline on device-resident inputs; the list of this epoch is already in the handle's buffers

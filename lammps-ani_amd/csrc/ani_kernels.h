@@ -35,6 +35,8 @@ struct GemmArgs {
   float alpha, inv_alpha;  // CELU
 };
 void launch_gemm(const GemmArgs& g, Epilogue epi, hipStream_t st);
+// one launch for several problems of the same epilogue (all species buckets of one layer)
+void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st);
 
 // x (double [ntotal*3]) + species -> float4 {x,y,z,species bits}
 void launch_pack(const double* d_x, const int* d_species, int ntotal, float4* xyzs, hipStream_t st);

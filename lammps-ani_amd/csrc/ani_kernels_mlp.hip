@@ -6,21 +6,34 @@
 //   backward layer l : A = dE/dz_l,                  Bt = W_l^T ([in][out], transposed copy made at load time)
 // so both operands are K-contiguous and one kernel serves all of them.
 //
-// Tiling (one workgroup = 4 waves = 128 rows x 32*NT columns):
-//   wave w owns rows [32w, 32w+32) and ALL 32*NT columns: NT accumulators of 32x32 (16 VGPRs each);
-//   K is walked in slabs of 32 staged through LDS (row stride 36 floats = 144 B = 9*16 B, so the
-//   ds_read_b128 fragment reads are bank-conflict free); within a slab, lane l (r = l&31, h = l>>5) reads
-//   4 consecutive k of row r at k = 8*ks + 4*h and feeds them to 4 successive MFMAs — the k order inside a
-//   slab is permuted identically for A and B, which leaves the dot products unchanged.
-//   The next slab's global loads are issued before the current slab's MFMAs (register prefetch).
-// MFMA C layout (guide §3): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// Grouped launch: all species buckets (and ensemble members) of one layer go into ONE launch; a workgroup finds its
+// (problem, row tile, member, column block) from its block index.  MFMA time per workgroup is long (tens of
+// microseconds), so load balance across the 256 CUs is decided by tile granularity: WM selects 128-row tiles
+// (4 waves stacked in M, each owning all columns) or 64-row tiles (2x2 waves, each owning half the columns; 3
+// workgroups per CU) — the launcher picks the one with the smaller estimated makespan.
+//
+// Inside a workgroup: K is walked in slabs of 32 staged through LDS (row stride 36 floats = 144 B = 9*16 B, so the
+// ds_read_b128 fragment reads are bank-conflict free); lane l (r = l&31, h = l>>5) reads 4 consecutive k of row r at
+// k = 8*ks + 4*h and feeds them to 4 successive MFMAs — the k order inside a slab is permuted identically for A and
+// B, which leaves the dot products unchanged.  The next slab's global loads are issued before the current slab's
+// MFMAs (register prefetch).  MFMA C layout (guide §3): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include <cstdlib>
+
 #include "ani_kernels.h"
 
 namespace ani {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int LDS_LD = 36;  // floats per staged row (32 + 4 pad)
+constexpr int LDS_LD = 36;       // floats per staged row (32 + 4 pad)
+constexpr int kMaxProblems = 16; // species buckets per grouped launch
+
+struct GroupArgs {
+  GemmArgs p[kMaxProblems];
+  int tile_start[kMaxProblems + 1];  // prefix of workgroups per problem
+  int tiles_m[kMaxProblems];
+  int nprob;
+};
 
 __device__ __forceinline__ float celu_f(float z, float alpha, float inv_alpha) {
   return z > 0.f ? z : alpha * expm1f(z * inv_alpha);
@@ -30,45 +43,71 @@ __device__ __forceinline__ float dcelu_from_h(float h, float inv_alpha) {
   return h > 0.f ? 1.f : fmaf(h, inv_alpha, 1.f);
 }
 
-template <int NT, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
-  __shared__ float lds[(kRowTile + 32 * NT) * LDS_LD];
+template <int WM, int EPI>
+__global__ __launch_bounds__(256, (WM == 4 ? 2 : 3)) void gemm_grouped(GroupArgs G) {
+  constexpr int WN = 4 / WM;        // waves along N
+  constexpr int R = 32 * WM;        // rows per workgroup
+  constexpr int NTW = 8 / WN;       // max 32-column tiles per wave
+  __shared__ float lds[(R + 256) * LDS_LD];
   float* As = lds;
-  float* Bs = lds + kRowTile * LDS_LD;
+  float* Bs = lds + R * LDS_LD;
+
+  // ---- which problem / tile ----
+  int pi = 0;
+  while (pi + 1 < G.nprob && (int)blockIdx.x >= G.tile_start[pi + 1]) pi++;
+  const GemmArgs& g = G.p[pi];
+  const int tiles_m = G.tiles_m[pi];
+  int local = blockIdx.x - G.tile_start[pi];
+  const int per_nb = tiles_m * g.batch;
+  const int nb = local / per_nb;
+  local -= nb * per_nb;
+  // members of one row tile sit 8 block ids apart -> same XCD (round-robin dispatch), they share the A tile in L2
+  const int grp = local / (8 * g.batch);
+  const int rem = local - grp * (8 * g.batch);
+  const int gs = min(8, tiles_m - grp * 8);
+  const int b = rem / gs;
+  const int tile_m = grp * 8 + (rem - b * gs);
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.y;
-  const int n0 = blockIdx.z * (32 * NT);
-  const int row0 = g.row0 + blockIdx.x * kRowTile;
+  const int wm = wave / WN, wn = wave % WN;
+  const int n0 = nb * 256;
+  const int row0 = g.row0 + tile_m * R;
   const int K = g.K, N = g.N;
+  const int ntiles = min(8, (N - n0 + 31) >> 5);           // 32-column tiles of this workgroup
+  const int per = (ntiles + WN - 1) / WN;                   // tiles per wave column
+  const int t0 = wn * per;                                  // first tile of this wave
+  const int tcnt = max(0, min(per, ntiles - t0));           // tiles of this wave (wave-uniform)
 
   const float* __restrict__ A = g.A + (long long)b * g.sA + (long long)row0 * g.lda;
   const float* __restrict__ Bt = g.Bt + (long long)b * g.sB + (long long)n0 * g.ldb;
 
-  f32x16 acc[NT];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++)
+  for (int nt = 0; nt < NTW; nt++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
 
-  float4 pa[4], pb[NT];
+  constexpr int PA = R / 32;  // float4 per thread for the A slab
+  float4 pa[PA], pb[8];
   const int cr = tid >> 3;         // staged row handled by this thread (per 32-row group)
   const int ck = (tid & 7) * 4;    // k offset inside the slab
+  const int brows = 32 * ntiles;
 
   auto gload = [&](int k0) {
     const int kc = k0 + ck;
     const bool kin = kc < K;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < PA; i++) {
       const int r = cr + 32 * i;
       pa[i] = kin ? *reinterpret_cast<const float4*>(A + (long long)r * g.lda + kc) : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < NT; i++) {
+    for (int i = 0; i < 8; i++) {
       const int r = cr + 32 * i;
-      pb[i] = (kin && (n0 + r) < N) ? *reinterpret_cast<const float4*>(Bt + (long long)r * g.ldb + kc) : make_float4(0, 0, 0, 0);
+      if (r < brows)  // wave-uniform per i
+        pb[i] = (kin && (n0 + r) < N) ? *reinterpret_cast<const float4*>(Bt + (long long)r * g.ldb + kc) : make_float4(0, 0, 0, 0);
     }
   };
 
@@ -77,33 +116,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   for (int kt = 0; kt < nkt; kt++) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; i++) *reinterpret_cast<float4*>(As + (cr + 32 * i) * LDS_LD + ck) = pa[i];
+    for (int i = 0; i < PA; i++) *reinterpret_cast<float4*>(As + (cr + 32 * i) * LDS_LD + ck) = pa[i];
 #pragma unroll
-    for (int i = 0; i < NT; i++) *reinterpret_cast<float4*>(Bs + (cr + 32 * i) * LDS_LD + ck) = pb[i];
+    for (int i = 0; i < 8; i++)
+      if (cr + 32 * i < brows) *reinterpret_cast<float4*>(Bs + (cr + 32 * i) * LDS_LD + ck) = pb[i];
     __syncthreads();
     if (kt + 1 < nkt) gload((kt + 1) << 5);
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-      const float4 a4 = *reinterpret_cast<const float4*>(As + (32 * wave + lr) * LDS_LD + ks * 8 + 4 * lh);
+      const float4 a4 = *reinterpret_cast<const float4*>(As + (32 * wm + lr) * LDS_LD + ks * 8 + 4 * lh);
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        const float4 b4 = *reinterpret_cast<const float4*>(Bs + (32 * nt + lr) * LDS_LD + ks * 8 + 4 * lh);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[nt], 0, 0, 0);
+      for (int nt = 0; nt < NTW; nt++) {
+        if (nt < tcnt) {
+          const float4 b4 = *reinterpret_cast<const float4*>(Bs + (32 * (t0 + nt) + lr) * LDS_LD + ks * 8 + 4 * lh);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[nt], 0, 0, 0);
+        }
       }
     }
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------
   float* __restrict__ C = g.C + (long long)b * g.sC;
-  const int mbase = row0 + 32 * wave + 4 * lh;
+  const int mbase = row0 + 32 * wm + 4 * lh;
   if constexpr (EPI == EPI_PLAIN) {
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const int n = n0 + 32 * nt + lr;
-      if (n < N) {
+    for (int nt = 0; nt < NTW; nt++) {
+      const int n = n0 + 32 * (t0 + nt) + lr;
+      if (nt < tcnt && n < N) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -114,9 +156,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   } else if constexpr (EPI == EPI_CELU) {
     const float* bias = g.bias + (long long)b * g.sBias;
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const int n = n0 + 32 * nt + lr;
-      if (n < N) {
+    for (int nt = 0; nt < NTW; nt++) {
+      const int n = n0 + 32 * (t0 + nt) + lr;
+      if (nt < tcnt && n < N) {
         const float bv = bias[n];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -128,9 +170,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   } else if constexpr (EPI == EPI_BWD) {
     const float* H = g.aux + (long long)b * g.sAux;
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const int n = n0 + 32 * nt + lr;
-      if (n < N) {
+    for (int nt = 0; nt < NTW; nt++) {
+      const int n = n0 + 32 * (t0 + nt) + lr;
+      if (nt < tcnt && n < N) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
@@ -142,19 +184,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   } else {  // EPI_LAST: last hidden layer fused with the 1-wide output layer and the backward seed
     const float* bias = g.bias + (long long)b * g.sBias;
     const float* w = g.aux + (long long)b * g.sAux;
-    float esum[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) esum[r] = 0.f;
-    float valid[16];
+    float esum[16], valid[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
+      esum[r] = 0.f;
       const int m = mbase + (r & 3) + 8 * (r >> 2);
       valid[r] = g.centre_of_row[m] >= 0 ? g.scale : 0.f;
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const int n = n0 + 32 * nt + lr;
-      if (n < N) {
+    for (int nt = 0; nt < NTW; nt++) {
+      const int n = n0 + 32 * (t0 + nt) + lr;
+      if (nt < tcnt && n < N) {
         const float bv = bias[n], wv = w[n];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -166,8 +206,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         }
       }
     }
-    const float bl = g.bias_last[b];
-    float* e_out = g.e_out + (long long)b * g.sE;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       float v = esum[r];
@@ -176,40 +214,101 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       v += __shfl_xor(v, 4);
       v += __shfl_xor(v, 2);
       v += __shfl_xor(v, 1);
+      esum[r] = v;
+    }
+    const float bl = g.bias_last[b];
+    float* e_out = g.e_out + (long long)b * g.sE;
+    if constexpr (WN == 1) {
       if (lr == 0) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        e_out[m] = valid[r] * (v + bl);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          e_out[m] = valid[r] * (esum[r] + bl);
+        }
+      }
+    } else {
+      // row sums are split over the WN wave columns: combine through LDS (staging buffers are free now)
+      __syncthreads();
+      float* red = lds;  // [WN][R]
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wn * R + 32 * wm + 4 * lh + (r & 3) + 8 * (r >> 2)] = esum[r];
+      }
+      __syncthreads();
+      if (wn == 0 && lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int rl = 32 * wm + 4 * lh + (r & 3) + 8 * (r >> 2);
+          float v = 0.f;
+#pragma unroll
+          for (int c = 0; c < WN; c++) v += red[c * R + rl];
+          e_out[row0 + rl] = valid[r] * (v + bl);
+        }
       }
     }
   }
 }
 
-template <int EPI>
-static void launch_nt(const GemmArgs& g, int NT, dim3 grid, hipStream_t st) {
-  switch (NT) {
-    case 1: hipLaunchKernelGGL((gemm_kernel<1, EPI>), grid, dim3(256), 0, st, g); break;
-    case 2: hipLaunchKernelGGL((gemm_kernel<2, EPI>), grid, dim3(256), 0, st, g); break;
-    case 3: hipLaunchKernelGGL((gemm_kernel<3, EPI>), grid, dim3(256), 0, st, g); break;
-    case 4: hipLaunchKernelGGL((gemm_kernel<4, EPI>), grid, dim3(256), 0, st, g); break;
-    case 5: hipLaunchKernelGGL((gemm_kernel<5, EPI>), grid, dim3(256), 0, st, g); break;
-    case 6: hipLaunchKernelGGL((gemm_kernel<6, EPI>), grid, dim3(256), 0, st, g); break;
-    case 7: hipLaunchKernelGGL((gemm_kernel<7, EPI>), grid, dim3(256), 0, st, g); break;
-    default: hipLaunchKernelGGL((gemm_kernel<8, EPI>), grid, dim3(256), 0, st, g); break;
+template <int WM>
+static void launch_wm(const GroupArgs& G, Epilogue epi, int total, hipStream_t st) {
+  const dim3 grid(total), block(256);
+  switch (epi) {
+    case EPI_PLAIN: hipLaunchKernelGGL((gemm_grouped<WM, EPI_PLAIN>), grid, block, 0, st, G); break;
+    case EPI_CELU: hipLaunchKernelGGL((gemm_grouped<WM, EPI_CELU>), grid, block, 0, st, G); break;
+    case EPI_LAST: hipLaunchKernelGGL((gemm_grouped<WM, EPI_LAST>), grid, block, 0, st, G); break;
+    case EPI_BWD: hipLaunchKernelGGL((gemm_grouped<WM, EPI_BWD>), grid, block, 0, st, G); break;
   }
 }
 
-void launch_gemm(const GemmArgs& g, Epilogue epi, hipStream_t st) {
-  if (g.rows <= 0 || g.N <= 0) return;
-  const int ntiles = (g.N + 31) / 32;
-  const int NT = ntiles > 8 ? 8 : ntiles;
-  const int nblocks = (ntiles + NT - 1) / NT;
-  dim3 grid(g.rows / kRowTile, g.batch, nblocks);
-  switch (epi) {
-    case EPI_PLAIN: launch_nt<EPI_PLAIN>(g, NT, grid, st); break;
-    case EPI_CELU: launch_nt<EPI_CELU>(g, NT, grid, st); break;
-    case EPI_LAST: launch_nt<EPI_LAST>(g, NT, grid, st); break;
-    case EPI_BWD: launch_nt<EPI_BWD>(g, NT, grid, st); break;
+// estimated makespan (in units of one CU doing one row x one column-tile x K work) of a tile height R
+static double makespan(const GemmArgs* probs, int nprob, int R, int ncu) {
+  double total = 0, biggest = 0;
+  for (int i = 0; i < nprob; i++) {
+    const GemmArgs& g = probs[i];
+    if (g.rows <= 0 || g.N <= 0) continue;
+    const int tiles_m = (g.rows + R - 1) / R;
+    const int nblocks = (g.N + 255) / 256;
+    const double per_tile = (double)R * ((g.N + nblocks - 1) / nblocks) * g.K;
+    total += per_tile * tiles_m * nblocks * g.batch;
+    biggest = per_tile > biggest ? per_tile : biggest;
+  }
+  // greedy dispatch: every CU is busy until the work runs out, then at most one more tile
+  return total / ncu + biggest;
+}
+
+void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st) {
+  static const int forced = [] { const char* e = getenv("ANI_GEMM_WM"); return e ? atoi(e) : 0; }();
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  for (int base = 0; base < nprob; base += kMaxProblems) {
+    const int np = nprob - base < kMaxProblems ? nprob - base : kMaxProblems;
+    int WM = forced;
+    if (WM != 2 && WM != 4) WM = makespan(probs + base, np, 64, ncu) < 0.97 * makespan(probs + base, np, 128, ncu) ? 2 : 4;
+    const int R = 32 * WM;
+    GroupArgs G;
+    G.nprob = 0;
+    int total = 0;
+    for (int i = 0; i < np; i++) {
+      const GemmArgs& g = probs[base + i];
+      if (g.rows <= 0 || g.N <= 0 || g.batch <= 0) continue;
+      const int tiles_m = g.rows / R;  // rows is a multiple of kRowTile = 128
+      const int nblocks = (g.N + 255) / 256;
+      G.p[G.nprob] = g;
+      G.tiles_m[G.nprob] = tiles_m;
+      G.tile_start[G.nprob] = total;
+      total += tiles_m * g.batch * nblocks;
+      G.nprob++;
+    }
+    G.tile_start[G.nprob] = total;
+    if (total == 0) continue;
+    if (WM == 4) launch_wm<4>(G, epi, total, st);
+    else launch_wm<2>(G, epi, total, st);
   }
 }
+
+void launch_gemm(const GemmArgs& g, Epilogue epi, hipStream_t st) { launch_gemm_group(&g, 1, epi, st); }
 
 }  // namespace ani
