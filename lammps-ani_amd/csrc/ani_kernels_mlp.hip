@@ -43,8 +43,11 @@ __device__ __forceinline__ float dcelu_from_h(float h, float inv_alpha) {
   return h > 0.f ? 1.f : fmaf(h, inv_alpha, 1.f);
 }
 
+#ifndef ANI_GEMM_LB2
+#define ANI_GEMM_LB2 3  // workgroups per CU the 64-row variant is compiled for
+#endif
 template <int WM, int EPI>
-__global__ __launch_bounds__(256, (WM == 4 ? 2 : 3)) void gemm_grouped(GroupArgs G) {
+__global__ __launch_bounds__(256, (WM == 4 ? 2 : ANI_GEMM_LB2)) void gemm_grouped(GroupArgs G) {
   constexpr int WN = 4 / WM;        // waves along N
   constexpr int R = 32 * WM;        // rows per workgroup
   constexpr int NTW = 8 / WN;       // max 32-column tiles per wave
@@ -112,7 +115,16 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 3)) void gemm_grouped(GroupArgs
   };
 
   const int nkt = (K + 31) >> 5;
-  gload(0);
+  // Every workgroup of a problem streams the SAME Bt slabs; started together they would all hit the same L2 lines
+  // (one channel) at the same time.  Each workgroup therefore walks K from its own starting slab and wraps around:
+  // the sum over k is the same set of terms in a rotated order.
+#ifdef ANI_GEMM_NO_KROT
+  const int rot = 0;
+#else
+  const int rot = (int)((blockIdx.x * 11u) % (unsigned)nkt);
+#endif
+  auto slab_k0 = [&](int kt) { int t = kt + rot; if (t >= nkt) t -= nkt; return t << 5; };
+  gload(slab_k0(0));
   for (int kt = 0; kt < nkt; kt++) {
     __syncthreads();
 #pragma unroll
@@ -121,7 +133,9 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 3)) void gemm_grouped(GroupArgs
     for (int i = 0; i < 8; i++)
       if (cr + 32 * i < brows) *reinterpret_cast<float4*>(Bs + (cr + 32 * i) * LDS_LD + ck) = pb[i];
     __syncthreads();
-    if (kt + 1 < nkt) gload((kt + 1) << 5);
+#ifndef ABL_NO_GLOAD
+    if (kt + 1 < nkt) gload(slab_k0(kt + 1));
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
       const float4 a4 = *reinterpret_cast<const float4*>(As + (32 * wm + lr) * LDS_LD + ks * 8 + 4 * lh);
@@ -129,6 +143,10 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : 3)) void gemm_grouped(GroupArgs
       for (int nt = 0; nt < NTW; nt++) {
         if (nt < tcnt) {
           const float4 b4 = *reinterpret_cast<const float4*>(Bs + (32 * (t0 + nt) + lr) * LDS_LD + ks * 8 + 4 * lh);
+#ifdef ABL_NO_MFMA
+          asm volatile("" ::"v"(a4.x), "v"(b4.x), "v"(b4.w), "v"(a4.w));
+          continue;
+#endif
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[nt], 0, 0, 0);
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[nt], 0, 0, 0);
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[nt], 0, 0, 0);
