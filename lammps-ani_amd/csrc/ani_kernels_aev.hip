@@ -163,13 +163,38 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd) {
 // info = row_info[row] = {centre atom i, first list slot, list length, centre position ii}.
 // The list is walked in super-chunks of 4 x 64 candidates: all jlist loads of a super-chunk are issued first, then
 // all position gathers, so a typical ~150-neighbour centre costs two dependent memory round trips, not six.
+// The first super-chunk arrives preloaded (Prefetched: issued one centre ahead by the persistent loop of the kernel).
+struct Prefetched {
+  int4 info;
+  float4 xi;
+  int jj[4];
+  float4 xx[4];
+};
+__device__ __forceinline__ int4 load_info(const AevArgs& a, int row) {
+  return row < a.nrows ? a.row_info[row] : make_int4(-1, 0, 0, -1);
+}
+__device__ __forceinline__ void load_j(const AevArgs& a, const int4 info, int lane, int (&jj)[4]) {
+  const int i = info.x < 0 ? 0 : info.x;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int q = 64 * c + lane;
+    jj[c] = q < info.z ? a.jlist[info.y + q] : i;
+  }
+}
+__device__ __forceinline__ void gather_x(const AevArgs& a, const int4 info, const int (&jj)[4], float4& xi, float4 (&xx)[4]) {
+  xi = a.xyzs[info.x < 0 ? 0 : info.x];
+#pragma unroll
+  for (int c = 0; c < 4; c++) xx[c] = a.xyzs[jj[c]];
+}
+
 template <bool BWD>
-__device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs& a, const int4 info, int lane, int cap, FastLds& L,
+__device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs& a, const Prefetched& pf, int lane, int cap, FastLds& L,
                                                int& nrad, int& nang, bool& over) {
+  const int4 info = pf.info;
   const int i = info.x;
   const int beg = info.y;
   const int n = info.z;
-  const float4 xi = a.xyzs[i];
+  const float4 xi = pf.xi;
   nrad = 0;
   nang = 0;
   over = false;
@@ -179,13 +204,18 @@ __device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs
   for (int base0 = 0; base0 < n; base0 += 256) {
     int jj[4];
     float4 xx[4];
+    if (base0 == 0) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int q = base0 + 64 * c + lane;
-      jj[c] = q < n ? a.jlist[beg + q] : i;
+      for (int c = 0; c < 4; c++) { jj[c] = pf.jj[c]; xx[c] = pf.xx[c]; }
+    } else {  // more than 256 list entries: rare, loaded in place
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int q = base0 + 64 * c + lane;
+        jj[c] = q < n ? a.jlist[beg + q] : i;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) xx[c] = a.xyzs[jj[c]];
     }
-#pragma unroll
-    for (int c = 0; c < 4; c++) xx[c] = a.xyzs[jj[c]];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const int base = base0 + 64 * c;
@@ -298,24 +328,18 @@ __device__ __forceinline__ void stream_pair(const FastLds& L, int nbk, int t, in
 }
 
 template <int NA, int NZ>
-__global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, AevArgs a, int cap) {
-  extern __shared__ float4 smem4[];
+__device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row, const Prefetched& pf,
+                                               int lane) {
   constexpr int NR = 16, Q = 64 / NA;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * kWaves + wave;
-  if (row >= a.nrows) return;
-  const int4 info = a.row_info[row];
-  if (info.x < 0) return;  // bucket padding: row stays zero (cleared at rebuild)
-  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, false), cap, false);
-
   for (int e = lane; e < kAevMax / 4; e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
   int nrad, nang;
   bool over;
-  compact_sorted<false>(p, a, info, lane, cap, L, nrad, nang, over);
+  compact_sorted<false>(p, a, pf, lane, cap, L, nrad, nang, over);
   if (over && lane == 0) atomicOr(a.err_flag, 1);
   wave_sync();
 
   // ---- radial: per species group, lanes = (slot q, shift k) ----
+#ifndef ABLF_NO_RAD
   {
     const int q = lane >> 4, k = lane & 15;
     const float shf = p.ShfR[k];
@@ -333,6 +357,7 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, Aev
       if (q == 0) L.row[s * NR + k] = 0.25f * acc;
     }
   }
+#endif
 
   // ---- angular ----
   int nbk;
@@ -363,7 +388,11 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, Aev
     for (int z = 0; z < NZ; z++) acc[z] = 0.f;
   };
 
+#ifdef ABLF_NO_ANG
+  for (int base = 0; base < 0; base += 64) {
+#else
   for (int base = 0; base < total; base += 64) {
+#endif
     // phase 1: lane = pair
     {
       int ia, ib, outoff;
@@ -406,27 +435,54 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, Aev
   float4* dst = reinterpret_cast<float4*>(a.aev + (long long)row * p.aev_stride);
   const int n4 = p.aev_stride >> 2;
   for (int e = lane; e < n4; e += 64) dst[e] = reinterpret_cast<const float4*>(L.row)[e];
+  wave_sync();  // the LDS slice is reused by this wave's next centre
+}
+
+// Persistent waves: wave w handles rows w, w + W, w + 2W, ...  The three dependent loads of a centre
+// (row_info -> jlist -> positions) are software-pipelined across centres: while centre c is being processed, the
+// position gathers of c+1, the list loads of c+2 and the row_info of c+3 are in flight.
+#define ANI_PERSISTENT_LOOP(KW, PRE_CALL, CENTRE_CALL)                                                   \
+  const int nw = gridDim.x * KW;                                                                          \
+  int row = blockIdx.x * KW + wave;                                                                       \
+  Prefetched cur, nxt;                                                                                    \
+  cur.info = load_info(a, row);                                                                           \
+  nxt.info = load_info(a, row + nw);                                                                      \
+  int4 info2 = load_info(a, row + 2 * nw);                                                                \
+  load_j(a, cur.info, lane, cur.jj);                                                                      \
+  load_j(a, nxt.info, lane, nxt.jj);                                                                      \
+  gather_x(a, cur.info, cur.jj, cur.xi, cur.xx);                                                          \
+  while (row < a.nrows) {                                                                                 \
+    PRE_CALL;                                                                                             \
+    gather_x(a, nxt.info, nxt.jj, nxt.xi, nxt.xx);                                                        \
+    int jj2[4];                                                                                           \
+    load_j(a, info2, lane, jj2);                                                                          \
+    const int4 info3 = load_info(a, row + 3 * nw);                                                        \
+    if (cur.info.x >= 0) { CENTRE_CALL; }                                                                 \
+    cur = nxt;                                                                                            \
+    nxt.info = info2;                                                                                     \
+    _Pragma("unroll") for (int c = 0; c < 4; c++) nxt.jj[c] = jj2[c];                                     \
+    info2 = info3;                                                                                        \
+    row += nw;                                                                                            \
+  }
+
+template <int NA, int NZ>
+__global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, AevArgs a, int cap) {
+  extern __shared__ float4 smem4[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, false), cap, false);
+  ANI_PERSISTENT_LOOP(kWaves, (void)0, (forward_centre<NA, NZ>(p, a, cap, L, row, cur, lane)))
 }
 
 template <int NA, int NZ>
-__global__ __launch_bounds__(64 * kWavesB) void aev_backward_fast(AevParams p, AevArgs a, int cap) {
-  extern __shared__ float4 smem4[];
+__device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row, const Prefetched& pf,
+                                                const float4 (&grow)[4], int lane) {
   constexpr int NR = 16;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * kWavesB + wave;
-  if (row >= a.nrows) return;
-  const int4 info = a.row_info[row];
-  if (info.x < 0) return;
-  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, true), cap, true);
-
-  {
-    const float4* g4 = reinterpret_cast<const float4*>(a.gaev + (long long)row * p.aev_stride);
-    const int n4 = p.aev_stride >> 2;
-    for (int e = lane; e < n4; e += 64) reinterpret_cast<float4*>(L.row)[e] = g4[e];
-  }
+  const int4 info = pf.info;
+#pragma unroll
+  for (int c = 0; c < 4; c++) reinterpret_cast<float4*>(L.row)[lane + 64 * c] = grow[c];
   int nrad, nang;
   bool over;
-  compact_sorted<true>(p, a, info, lane, cap, L, nrad, nang, over);
+  compact_sorted<true>(p, a, pf, lane, cap, L, nrad, nang, over);
   if (over && lane == 0) atomicOr(a.err_flag, 1);
   wave_sync();
 
@@ -434,7 +490,12 @@ __global__ __launch_bounds__(64 * kWavesB) void aev_backward_fast(AevParams p, A
   {
     const float cR = -p.EtaR * kLog2e;
     const float rev = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;
+#ifdef ABL_NO_RAD
+    for (int t = lane; t < nrad; t += 64) { L.gd[3 * t] = 0.f; L.gd[3 * t + 1] = 0.f; L.gd[3 * t + 2] = 0.f; }
+    for (int t = lane; t < 0; t += 64) {
+#else
     for (int t = lane; t < nrad; t += 64) {
+#endif
       int s = 0;
       for (int k = 1; k < p.S; k++) s += (t >= L.rstart[k]) ? 1 : 0;
       const float* gg = L.row + s * NR;
@@ -572,6 +633,25 @@ __global__ __launch_bounds__(64 * kWavesB) void aev_backward_fast(AevParams p, A
       if (lane == 0) atomicAdd(&a.virial[k], -(double)sv);
     }
   }
+  wave_sync();  // the LDS slice is reused by this wave's next centre
+}
+
+template <int NA, int NZ>
+__global__ __launch_bounds__(64 * kWavesB) void aev_backward_fast(AevParams p, AevArgs a, int cap) {
+  extern __shared__ float4 smem4[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, true), cap, true);
+  // dE/dAEV row of the current centre: 4 x 16 B per lane, issued BEFORE this iteration's prefetch loads so that the
+  // wait for it (vmcnt counts in order) leaves the younger prefetches in flight
+  float4 grow[4];
+  const int n4 = p.aev_stride >> 2;
+  ANI_PERSISTENT_LOOP(kWavesB,
+                      {
+                        const float4* g4 = reinterpret_cast<const float4*>(a.gaev + (long long)row * p.aev_stride);
+                        _Pragma("unroll") for (int c = 0; c < 4; c++) grow[c] =
+                            (cur.info.x >= 0 && lane + 64 * c < n4) ? g4[lane + 64 * c] : make_float4(0, 0, 0, 0);
+                      },
+                      (backward_centre<NA, NZ>(p, a, cap, L, row, cur, grow, lane)))
 }
 
 // =====================================================================================================
@@ -818,6 +898,24 @@ bool aev_fast_path(const AevParams& p, int max_numneigh) {
   return (size_t)fast_wave_floats(c, true) * 4 * kWavesB <= 160 * 1024 && (size_t)fast_wave_floats(c, false) * 4 * kWaves <= 160 * 1024;
 }
 
+static int num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    return v > 0 ? v : 256;
+  }();
+  return n;
+}
+// persistent grid of the fast path: as many workgroups as fit on the chip by LDS (at most 8 per CU)
+static int persistent_blocks(int nrows, int waves_per_block, size_t lds_bytes) {
+  int per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  const int need = (nrows + waves_per_block - 1) / waves_per_block;
+  const int fit = num_cus() * per_cu;
+  return need < fit ? need : fit;
+}
+
 void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
   if (a.nrows <= 0) return;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
@@ -828,11 +926,11 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
     if (fast_kind(p) == 1) {
       static bool once = (hipFuncSetAttribute((const void*)aev_forward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_forward_fast<8, 4>), grid, block, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_forward_fast<8, 4>), dim3(persistent_blocks(a.nrows, kWaves, lds)), block, lds, st, p, a, cap);
     } else {
       static bool once = (hipFuncSetAttribute((const void*)aev_forward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_forward_fast<4, 8>), grid, block, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_forward_fast<4, 8>), dim3(persistent_blocks(a.nrows, kWaves, lds)), block, lds, st, p, a, cap);
     }
   } else {
     hipLaunchKernelGGL(aev_forward_generic, grid, block, 0, st, p, a);
@@ -850,11 +948,11 @@ void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
     if (fast_kind(p) == 1) {
       static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_backward_fast<8, 4>), gridB, blockB, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_backward_fast<8, 4>), dim3(persistent_blocks(a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap);
     } else {
       static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_backward_fast<4, 8>), gridB, blockB, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_backward_fast<4, 8>), dim3(persistent_blocks(a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap);
     }
   } else {
     hipLaunchKernelGGL(aev_backward_generic, grid, block, 0, st, p, a);
