@@ -37,11 +37,14 @@ PEAK_HBM_GBS = 8000.0          # same table (spec; ~6.3 TB/s achievable)
 PUBLISHED_NS_DAY = {(100002, 1): 1.495}
 
 
-def mlp_flops_per_step(model, counts):
-    """4 * M * sum_s n_s * P_s (forward 2P + input-gradient backward 2P), SURVEY.md §8(d)."""
+def mlp_flops_per_step(model, counts, aev_cols=None):
+    """4 * M * sum_s n_s * P_s (forward 2P + input-gradient backward 2P), SURVEY.md §8(d).
+    aev_cols: first-layer width actually contracted (the AEV columns of the species present); None = full AEV."""
     tot = 0
     for s, n in enumerate(counts):
-        d = model.dims[s]
+        d = list(model.dims[s])
+        if aev_cols is not None:
+            d[0] = aev_cols
         P = sum(d[l] * d[l + 1] for l in range(len(d) - 1))
         tot += n * P
     return 4.0 * model.num_models * tot
@@ -64,6 +67,8 @@ def main():
     ap.add_argument("--aev", default="cuaev", choices=["cuaev", "pyaev"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vflag", type=int, default=0)
+    ap.add_argument("--dense-aev", action="store_true", help="keep the AEV columns of absent species (full 1008-wide rows)")
+    ap.add_argument("--no-dense-pass", action="store_true", help="skip the extra timed pass with the full-width AEV")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,6 +93,8 @@ def main():
     grid = comm.grid_for(world)
     inp = hx.decompose(system, grid, rank, cutoff=5.1, skin=2.0)
     ani = ani_hip.ANI(mpath, local_rank, -1, use_cuaev=(args.aev == "cuaev"), use_fullnbr=True, use_single=True)
+    if args.dense_aev:
+        ani.set_option("prune_absent_species", 0)
 
     d_x = torch.from_numpy(inp.x.reshape(-1)).to(dev)
     d_species = torch.from_numpy(inp.species.astype(np.int32)).to(dev)
@@ -112,18 +119,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    step(0)  # list upload + bucketing: rebuild work, untimed
-    for w in range(args.warmup):
-        step(w + 1)
-    sync_all()
-    ani.phase_timing(True)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + 1 + k)
-    sync_all()
-    dt = time.perf_counter() - t0
-    phases = ani.phase_times()
-    ani.phase_timing(False)
+    def timed_run(nsteps):
+        step(0)  # list upload + bucketing: rebuild work, untimed
+        for w in range(args.warmup):
+            step(w + 1)
+        sync_all()
+        ani.phase_timing(True)
+        t0 = time.perf_counter()
+        for k in range(nsteps):
+            step(args.warmup + 1 + k)
+        sync_all()
+        dt_ = time.perf_counter() - t0
+        ph = ani.phase_times()
+        ani.phase_timing(False)
+        return dt_, ph
+
+    dense_pass = None
+    if world == 1 and not args.dense_aev and not args.no_dense_pass:
+        # secondary number: the same workload with the full 1008-wide AEV rows (columns of absent species kept)
+        ani.set_option("prune_absent_species", 0)
+        dtd, phd = timed_run(max(args.steps // 2, 1))
+        dense_pass = {"ms_per_step": dtd / max(args.steps // 2, 1) * 1e3, "value": max(args.steps // 2, 1) / dtd * 0.0432,
+                      "phase_ms": {k: phd[k] / max(phd["calls"], 1) for k in ("aev_fwd", "mlp", "aev_bwd")}}
+        ani.set_option("prune_absent_species", 1)
+    dt, phases = timed_run(args.steps)
     energy_local = float(d_ev[0].item())
     if not np.isfinite(energy_local):
         raise SystemExit("non-finite energy: LDS neighbour capacity exceeded or numerical failure")
@@ -153,11 +172,13 @@ def main():
         nlocal_r, ntotal_r, npairs_r = (int(allstats[r, i]) for i in (4, 5, 6))
         counts_box = np.bincount(system.types - 1, minlength=model.num_species)
         counts_r = counts_box * (nlocal_r / system.natoms)
-        flops = mlp_flops_per_step(model, counts_r)
-        bf, bb = aev_bytes_per_step(model.aev_len, nlocal_r, ntotal_r, npairs_r)
+        aev_cols = ani.debug_view().aev_active_length  # columns of the species present (1008 when all 7 occur)
+        flops = mlp_flops_per_step(model, counts_r, aev_cols)
+        flops_dense = mlp_flops_per_step(model, counts_r)
+        bf, bb = aev_bytes_per_step(aev_cols, nlocal_r, ntotal_r, npairs_r)
         mlp_roof = dict(bound="mfma", achieved=flops / (t_mlp * 1e-3) / 1e12 if t_mlp > 0 else None, peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", traffic=None, kernel="gemm_kernel (MLP forward+backward, 6 launches per species)",
-                        ms_per_step=t_mlp, flops_per_step=flops)
+                        ms_per_step=t_mlp, flops_per_step=flops, flops_per_step_full_width_aev=flops_dense, aev_columns=aev_cols)
         mlp_roof["frac"] = mlp_roof["achieved"] / PEAK_F32_MFMA_TFLOPS if mlp_roof["achieved"] else None
         aev_roof = dict(bound="hbm", achieved=(bf + bb) / ((t_fwd + t_bwd) * 1e-3) / 1e9 if t_fwd + t_bwd > 0 else None,
                         peak=PEAK_HBM_GBS, unit="GB/s", traffic=None, kernel="aev_forward_kernel + aev_backward_kernel",
@@ -174,10 +195,10 @@ def main():
             "config": {"workload": f"water-{args.atoms} (rho=0.98 g/cm3), ANI-2x shaped seeded weights, {args.models} model(s), "
                                    f"pair_style ani 5.1 <model> hip {args.models} {args.aev} full single, skin 2.0, static positions, list reused (ago>0)",
                        "atoms": args.atoms, "models": args.models, "grid": list(grid), "nlocal_rank0": inp.nlocal,
-                       "nghost_rank0": inp.nghost, "npairs_rank0": inp.npairs, "aev": args.aev, "vflag": args.vflag,
+                       "nghost_rank0": inp.nghost, "npairs_rank0": inp.npairs, "aev": args.aev, "vflag": args.vflag, "prune_absent_species": not args.dense_aev, "aev_columns": aev_cols,
                        "matom_steps_per_s": args.atoms * steps / dt / 1e6,
                        "vs_baseline_note": "published number is 1xA100 (examples/benchmark/README.md:78), different hardware"},
-            "roofline": dominant, "roofline_other": other,
+            "roofline": dominant, "roofline_other": other, "full_width_aev_pass": dense_pass,
             "phase_ms": {"aev_fwd": t_fwd, "mlp": t_mlp, "aev_bwd": t_bwd, "finish": t_other},
         }
         if world == 1 and not args.no_cpu_baseline:

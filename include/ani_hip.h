@@ -117,8 +117,21 @@ typedef struct {
   const float* d_gaev;             /* [nrows][aev_length]  dE/dAEV (Hartree) */
   const int* d_row_of_centre;      /* [nlocal] row of centre ii */
   int species_count[16];           /* centres per species */
+  int aev_stride;                  /* floats per row of d_aev / d_gaev */
+  int aev_active_length;           /* columns in use: the AEV entries of the species present in the system */
 } ani_debug_view;
 int ani_debug_get(ani_handle* h, ani_debug_view* out);
+/* out[c], c < aev_active_length: column of the model's full AEV that column c of d_aev holds */
+int ani_debug_colmap(ani_handle* h, int* out);
+
+/*
+ * Options (take effect at the next call with ago == 0):
+ *   "prune_absent_species" (default 1): AEV entries of species that occur nowhere in the system (neither as centre
+ *       nor as neighbour) are identically zero; with 1 the kernels work on the remaining columns only (ANI-2x water:
+ *       128 of 1008) and the first-layer products use the matching weight columns — the same sums without the zero
+ *       terms.  0 forces the full 1008-column layout.
+ */
+int ani_set_option(ani_handle* h, const char* name, int value);
 /* copy `bytes` from a device pointer of the view to host memory (synchronises the handle's stream first) */
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes);
 

@@ -20,7 +20,7 @@ HARTREE2KCALMOL = 627.5094738898777
 
 EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani_use_num_models", "ani_num_species",
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
-           "ani_compute_full_device", "ani_debug_get", "ani_debug_read", "ani_phase_timing", "ani_phase_times"]
+           "ani_compute_full_device", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times"]
 
 
 class AniError(RuntimeError):
@@ -30,7 +30,7 @@ class AniError(RuntimeError):
 class DebugView(C.Structure):
     _fields_ = [("nlocal", C.c_int), ("ntotal", C.c_int), ("nrows", C.c_int), ("npairs", C.c_int64),
                 ("d_aev", C.c_void_p), ("d_gaev", C.c_void_p), ("d_row_of_centre", C.c_void_p),
-                ("species_count", C.c_int * 16)]
+                ("species_count", C.c_int * 16), ("aev_stride", C.c_int), ("aev_active_length", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -70,6 +70,8 @@ def lib():
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ani_debug_get.argtypes = [C.c_void_p, C.POINTER(DebugView)]
         L.ani_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.ani_debug_colmap.argtypes = [C.c_void_p, C.c_void_p]
+        L.ani_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.ani_phase_timing.argtypes = [C.c_void_p, C.c_int]
         L.ani_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _lib = L
@@ -147,6 +149,15 @@ class ANI:
         out = np.empty(shape, dtype=dtype)
         self._check(self._lib.ani_debug_read(self._h, d_ptr, out.ctypes.data, out.nbytes))
         return out
+
+    def colmap(self) -> np.ndarray:
+        v = self.debug_view()
+        out = np.zeros(v.aev_active_length, dtype=np.int32)
+        self._check(self._lib.ani_debug_colmap(self._h, out.ctypes.data))
+        return out
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.ani_set_option(self._h, name.encode(), int(value)))
 
     def phase_timing(self, enable: bool):
         self._check(self._lib.ani_phase_timing(self._h, int(enable)))

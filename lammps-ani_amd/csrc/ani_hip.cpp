@@ -55,6 +55,8 @@ struct SpeciesNet {
   std::vector<float*> W;    // [L-1]   W[k]: [M][d[k+1]][kpad(k)]        forward, k = 0..L-2
   std::vector<float*> b;    // [L-1]   b[k]: [M][d[k+1]]
   std::vector<float*> WT;   // [L-1]   WT[k], k = 1..L-2: [M][d[k]][w(k+1)] ; WT[0]: [aev_len][M*w(1)]
+  float* W0c = nullptr;     // first layer restricted to the AEV columns of the species present: [M][d[1]][aev_stride']
+  float* WT0c = nullptr;    // and its transposed copy [aev_len'][M*w(1)]   (null when every species is present)
   float* w_out = nullptr;   // [M][w(L-1)]
   float* b_out = nullptr;   // [M]
   std::vector<int> w;       // w[k] = round_up(d[k],4), k = 0..L-1 (w[0] = aev_stride)
@@ -64,7 +66,12 @@ struct SpeciesNet {
 
 struct ani_handle {
   HostModel model;
-  AevParams ap;
+  AevParams ap;       // the model's full AEV layout
+  AevParams ap_run;   // the layout the kernels run with this epoch: ap restricted to the species present
+  SpeciesMap cmap{};  // species -> index among the species present
+  int active_mask = -1;
+  bool prune = true;  // ani_set_option("prune_absent_species")
+  std::vector<int> colmap;  // ap_run column -> ap column
   int device = 0;
   bool use_cuaev = true, use_fullnbr = true, use_single = true;
   hipStream_t stream = nullptr;
@@ -182,6 +189,70 @@ int upload_model(ani_handle* h) {
   return ANI_OK;
 }
 
+
+// AEV columns of species that do not occur in the system (centres or neighbours) are identically zero, so the
+// first-layer products only need the columns of the species present: exact same sums with the zero terms left out.
+// The AEV kernels then run with a compact layout (S' species, A' = 16 S' + 32 S'(S'+1)/2 columns) and the first layer /
+// dE/dAEV products use column-gathered weights.  Water with ANI-2x: 1008 -> 128 columns; C,H,N,O systems: 384.
+int specialize(ani_handle* h, int mask) {
+  const HostModel& m = h->model;
+  if (!h->prune) mask = (1 << m.S) - 1;
+  if (mask == h->active_mask) return ANI_OK;
+  for (auto& n : h->nets) {
+    if (n.W0c) (void)hipFree(n.W0c);
+    if (n.WT0c) (void)hipFree(n.WT0c);
+    n.W0c = n.WT0c = nullptr;
+  }
+  std::vector<int> act;
+  for (int s = 0; s < m.S; s++) {
+    h->cmap.m[s] = (int)act.size();
+    if (mask & (1 << s)) act.push_back(s);
+  }
+  for (int s = m.S; s < kMaxSpecies; s++) h->cmap.m[s] = 0;
+  const int na = (int)act.size();
+  h->ap_run = h->ap;
+  h->colmap.resize(m.aev_len);
+  for (int c = 0; c < m.aev_len; c++) h->colmap[c] = c;
+  h->active_mask = mask;
+  if (na == m.S || na == 0) {
+    for (int s = 0; s < m.S; s++) h->cmap.m[s] = s;
+    return ANI_OK;
+  }
+  const int nAZ = m.nA * m.nZ;
+  const int alen = na * m.nR + na * (na + 1) / 2 * nAZ;
+  const int astride = round_up(alen, 4);
+  AevParams& p = h->ap_run;
+  p.S = na; p.radial_len = na * m.nR; p.aev_len = alen; p.aev_stride = astride;
+  h->colmap.assign(alen, 0);
+  for (int cs = 0; cs < na; cs++)
+    for (int k = 0; k < m.nR; k++) h->colmap[cs * m.nR + k] = act[cs] * m.nR + k;
+  {
+    int b = 0;
+    for (int c1 = 0; c1 < na; c1++)
+      for (int c2 = c1; c2 < na; c2++, b++) {
+        const int lo = act[c1], hi = act[c2];
+        const int dense_b = lo * m.S - lo * (lo - 1) / 2 + (hi - lo);
+        for (int t = 0; t < nAZ; t++) h->colmap[na * m.nR + b * nAZ + t] = m.radial_len + dense_b * nAZ + t;
+      }
+  }
+  const int M = m.M;
+  for (int s = 0; s < m.S; s++) {
+    SpeciesNet& n = h->nets[s];
+    const int out = m.dims[s][1], in = m.dims[s][0], w1 = n.w[1];
+    std::vector<float> W((size_t)M * out * astride, 0.f), T((size_t)alen * M * w1, 0.f);
+    for (int a = 0; a < M; a++)
+      for (int o = 0; o < out; o++)
+        for (int c = 0; c < alen; c++) {
+          const float v = m.W[a][s][0][(size_t)o * in + h->colmap[c]];
+          W[((size_t)a * out + o) * astride + c] = v;
+          T[(size_t)c * M * w1 + (size_t)a * w1 + o] = v;
+        }
+    int rc = upload(h, &n.W0c, W); if (rc) return rc;
+    rc = upload(h, &n.WT0c, T); if (rc) return rc;
+  }
+  return ANI_OK;
+}
+
 // (re)build everything that depends on the neighbour list: offsets, species buckets, activation arena.
 // d_species/d_ilist/d_numneigh/d_jlist already hold this epoch's list in the handle's own buffers.
 int rebuild(ani_handle* h, hipStream_t st) {
@@ -202,10 +273,14 @@ int rebuild(ani_handle* h, hipStream_t st) {
   for (int s = 0; s < m.S; s++) { h->count[s] = info[s]; h->row_start[s] = info[kMaxSpecies + s]; }
   h->nrows = info[2 * kMaxSpecies];
   h->max_numneigh = info[2 * kMaxSpecies + 2];
+  {
+    const int rcs = specialize(h, info[2 * kMaxSpecies + 3]);
+    if (rcs) return rcs;
+  }
   // neighbour segments grouped by species: what lets the AEV kernels accumulate without atomics
   launch_sort_jlist(h->species.p, h->nbr_off.p, h->numneigh.p, h->jraw.p, h->jlist.p, nlocal, m.S, st);
 
-  const size_t stride = h->ap.aev_stride;
+  const size_t stride = h->ap_run.aev_stride;
   HIP_TRY(h, h->aev.reserve((size_t)std::max(h->nrows, 1) * stride));
   HIP_TRY(h, h->gaev.reserve((size_t)std::max(h->nrows, 1) * stride));
   HIP_TRY(h, hipMemsetAsync(h->aev.p, 0, (size_t)h->nrows * stride * sizeof(float), st));  // padding rows stay zero
@@ -261,10 +336,14 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
       const SpeciesNet& n = h->nets[s];
       const std::vector<int>& d = m.dims[s];
       GemmArgs g = base_args(s);
-      if (k == 0) { g.A = h->aev.p + (size_t)h->row_start[s] * h->ap.aev_stride; g.lda = h->ap.aev_stride; g.sA = 0; }
-      else { g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k]; }
-      g.K = n.w[k];
-      g.Bt = n.W[k]; g.ldb = n.w[k]; g.sB = (long long)d[k + 1] * n.w[k];
+      if (k == 0) {
+        const int ka = h->ap_run.aev_stride;  // first layer over the AEV columns of the species present
+        g.A = h->aev.p + (size_t)h->row_start[s] * ka; g.lda = ka; g.sA = 0;
+        g.K = ka; g.Bt = n.W0c ? n.W0c : n.W[0]; g.ldb = ka; g.sB = (long long)d[1] * ka;
+      } else {
+        g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k];
+        g.K = n.w[k]; g.Bt = n.W[k]; g.ldb = n.w[k]; g.sB = (long long)d[k + 1] * n.w[k];
+      }
       g.N = d[k + 1];
       g.bias = n.b[k]; g.sBias = d[k + 1];
       g.C = h->Hbuf[s][k + 1]; g.ldc = M * n.w[k + 1]; g.sC = n.w[k + 1];
@@ -302,9 +381,9 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
     GemmArgs g = base_args(s);
     g.batch = 1;
     g.A = h->Hbuf[s][1]; g.lda = M * n.w[1]; g.K = M * n.w[1];
-    g.Bt = n.WT[0]; g.ldb = M * n.w[1];
-    g.N = m.aev_len;
-    g.C = h->gaev.p + (size_t)h->row_start[s] * h->ap.aev_stride; g.ldc = h->ap.aev_stride;
+    g.Bt = n.WT0c ? n.WT0c : n.WT[0]; g.ldb = M * n.w[1];
+    g.N = h->ap_run.aev_len;
+    g.C = h->gaev.p + (size_t)h->row_start[s] * h->ap_run.aev_stride; g.ldc = h->ap_run.aev_stride;
     probs.push_back(g);
   }
   launch_gemm_group(probs.data(), (int)probs.size(), EPI_PLAIN, st);
@@ -330,7 +409,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   }
 
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[0], st));
-  launch_pack(d_x, h->species.p, h->ntotal, h->xyzs.p, st);
+  launch_pack(d_x, h->species.p, h->ntotal, h->cmap, h->xyzs.p, st);
   HIP_TRY(h, hipMemsetAsync(h->fbuf.p, 0, sizeof(float) * 3 * (size_t)h->ntotal, st));
   HIP_TRY(h, hipMemsetAsync(h->virial_acc.p, 0, sizeof(double) * 9, st));
 
@@ -339,11 +418,11 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   a.centre_of_row = h->centre_of_row.p; a.row_info = h->row_info.p; a.nrows = h->nrows; a.aev = h->aev.p; a.gaev = h->gaev.p; a.fbuf = h->fbuf.p;
   a.virial = vflag ? h->virial_acc.p : nullptr;
   a.err_flag = h->err_flag.p;
-  launch_aev_forward(h->ap, a, h->max_numneigh, st);
+  launch_aev_forward(h->ap_run, a, h->max_numneigh, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[1], st));
   compute_mlp(h, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[2], st));
-  launch_aev_backward(h->ap, a, h->max_numneigh, st);
+  launch_aev_backward(h->ap_run, a, h->max_numneigh, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[3], st));
 
   FinishArgs fa{};
@@ -443,6 +522,8 @@ void ani_destroy(ani_handle* h) {
     for (float* p : n.W) if (p) (void)hipFree(p);
     for (float* p : n.b) if (p) (void)hipFree(p);
     for (float* p : n.WT) if (p) (void)hipFree(p);
+    if (n.W0c) (void)hipFree(n.W0c);
+    if (n.WT0c) (void)hipFree(n.WT0c);
     if (n.w_out) (void)hipFree(n.w_out);
     if (n.b_out) (void)hipFree(n.b_out);
   }
@@ -568,8 +649,27 @@ int ani_debug_get(ani_handle* h, ani_debug_view* out) {
   memset(out, 0, sizeof(*out));
   out->nlocal = h->nlocal; out->ntotal = h->ntotal; out->nrows = h->nrows; out->npairs = h->npairs;
   out->d_aev = h->aev.p; out->d_gaev = h->gaev.p; out->d_row_of_centre = h->row_of_centre.p;
+  out->aev_stride = h->ap_run.aev_stride; out->aev_active_length = h->ap_run.aev_len;
   for (int s = 0; s < kMaxSpecies && s < 16; s++) out->species_count[s] = h->count[s];
   return ANI_OK;
+}
+
+int ani_debug_colmap(ani_handle* h, int* out) {
+  if (!h || !out) return ANI_ERR_ARG;
+  for (int c = 0; c < h->ap_run.aev_len && c < (int)h->colmap.size(); c++) out[c] = h->colmap[c];
+  return ANI_OK;
+}
+
+int ani_set_option(ani_handle* h, const char* name, int value) {
+  if (!h || !name) return ANI_ERR_ARG;
+  if (strcmp(name, "prune_absent_species") == 0) {
+    h->prune = value != 0;
+    h->have_list = false;  // takes effect at the next rebuild (ago = 0), which the caller must issue
+    h->active_mask = -1;
+    return ANI_OK;
+  }
+  h->err = std::string("unknown option '") + name + "'";
+  return ANI_ERR_ARG;
 }
 
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes) {

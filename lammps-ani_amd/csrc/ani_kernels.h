@@ -38,8 +38,9 @@ void launch_gemm(const GemmArgs& g, Epilogue epi, hipStream_t st);
 // one launch for several problems of the same epilogue (all species buckets of one layer)
 void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st);
 
-// x (double [ntotal*3]) + species -> float4 {x,y,z,species bits}
-void launch_pack(const double* d_x, const int* d_species, int ntotal, float4* xyzs, hipStream_t st);
+// x (double [ntotal*3]) + species -> float4 {x,y,z,bits of cmap[species]}
+struct SpeciesMap { int m[kMaxSpecies]; };
+void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, hipStream_t st);
 
 // rebuild-time preparation: neighbour offsets, species buckets.  All outputs device arrays.
 struct PrepOut {
@@ -47,7 +48,7 @@ struct PrepOut {
   int* row_of_centre;   // [nlocal]
   int* centre_of_row;   // [nrows_cap] (-1 = padding)
   int4* row_info;       // [nrows_cap] per AEV row: {i, list begin, list length, ii}; i = -1 for padding rows
-  int* bucket_info;     // [kBucketInfoInts]: count[s], row_start[s], nrows, bad_species flag, max numneigh
+  int* bucket_info;     // [kBucketInfoInts]: count[s], row_start[s], nrows, bad_species flag, max numneigh, species-present mask
 };
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
                     const PrepOut& o, hipStream_t st);

@@ -5,16 +5,20 @@
 
 namespace ani {
 
-__global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int ntotal, float4* __restrict__ out) {
+__global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int ntotal, SpeciesMap cmap,
+                            float4* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ntotal) return;
-  // coordinates.to(dtype): src/ani_csrc/ani.cpp:206-207
-  out[i] = make_float4((float)x[3 * i], (float)x[3 * i + 1], (float)x[3 * i + 2], __int_as_float(species[i]));
+  // coordinates.to(dtype): src/ani_csrc/ani.cpp:206-207.  The species stored next to the position is the index the
+  // AEV kernels use (compact index among the species present in this system, see ani_hip.cpp:specialize).
+  const int sp = species[i];
+  const int cs = (sp >= 0 && sp < kMaxSpecies) ? cmap.m[sp] : 0;
+  out[i] = make_float4((float)x[3 * i], (float)x[3 * i + 1], (float)x[3 * i + 2], __int_as_float(cs));
 }
 
-void launch_pack(const double* d_x, const int* d_species, int ntotal, float4* xyzs, hipStream_t st) {
+void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, hipStream_t st) {
   if (ntotal <= 0) return;
-  hipLaunchKernelGGL(pack_kernel, dim3((ntotal + 255) / 256), dim3(256), 0, st, d_x, d_species, ntotal, xyzs);
+  hipLaunchKernelGGL(pack_kernel, dim3((ntotal + 255) / 256), dim3(256), 0, st, d_x, d_species, ntotal, cmap, xyzs);
 }
 
 // ---- rebuild-time preparation ------------------------------------------------------------------------
@@ -75,11 +79,14 @@ __global__ __launch_bounds__(1024) void prepare_count_kernel(const int* __restri
   } else {
     // species outside [0,S): flag it (the reference would fail inside the network lookup)
     int bad = 0;
-    // every atom, ghosts included: neighbour species index the AEV row
+    // every atom, ghosts included: neighbour species index the AEV row; also record which species occur at all
+    int present = 0;
     for (int i = threadIdx.x; i < ntotal; i += blockDim.x) {
       const int sp = species[i];
       if (sp < 0 || sp >= S) bad = 1;
+      else present |= 1 << sp;
     }
+    if (present) atomicOr(&o.bucket_info[2 * kMaxSpecies + 3], present);
     for (int ii = threadIdx.x; ii < nlocal; ii += blockDim.x) {
       const int i = ilist[ii];
       if (i < 0 || i >= ntotal) bad = 1;

@@ -62,10 +62,10 @@ def test_hip_aev_matches_oracle(model_cache, hip):
     ani = hip.ANI(p, 0)
     ani.compute(inp, ago=0)
     v = ani.debug_view()
-    A = ani.aev_length
-    stride = (A + 3) // 4 * 4
+    A = v.aev_active_length
+    assert A == ani.aev_length  # all 7 species occur in this box: nothing to prune
     rows = ani.debug_read(v.d_row_of_centre, inp.nlocal, np.int32)
-    aev = ani.debug_read(v.d_aev, (v.nrows, stride), np.float32)
+    aev = ani.debug_read(v.d_aev, (v.nrows, v.aev_stride), np.float32)
     ref = Oracle(p).compute(inp, want_aev=True)
     np.testing.assert_allclose(aev[rows, :A], ref["aev"], rtol=0, atol=1e-5)
     # bucket padding rows stay zero
@@ -183,4 +183,32 @@ def test_hip_device_api_with_torch_plumbing(model_cache, hip):
     # after reverse_add: local rows = 1 + own force + (1 + ghost force) per ghost image folded in
     nimg = np.bincount(inp.owner_lidx, minlength=inp.nlocal)[:, None]
     np.testing.assert_allclose(d_f.view(-1, 3)[: inp.nlocal].cpu().numpy() - 1.0 - nimg, folded, rtol=0, atol=F_TOL)
+    ani.close()
+
+
+def test_hip_prunes_columns_of_absent_species(model_cache, hip):
+    """Water with the 7-species ANI-2x layout: only the H/O columns (128 of 1008) are computed; the columns that are
+    kept equal the oracle's, the dropped ones are exactly zero in the oracle, and energies/forces equal those of the
+    full-width run (option prune_absent_species = 0) to fp32 summation-order noise."""
+    from oracle import Oracle
+    p = model_cache("ani2x", 2, 2024)
+    inp = hx.decompose(hx.water_box(600, seed=11), cutoff=5.1, skin=2.0)
+    ref = Oracle(p).compute(inp, want_aev=True)
+    ani = hip.ANI(p, 0)
+    got = ani.compute(inp, ago=0)
+    v = ani.debug_view()
+    assert v.aev_active_length == 2 * 16 + 3 * 32 == 128
+    cm = ani.colmap()
+    rows = ani.debug_read(v.d_row_of_centre, inp.nlocal, np.int32)
+    aev = ani.debug_read(v.d_aev, (v.nrows, v.aev_stride), np.float32)
+    np.testing.assert_allclose(aev[rows][:, : len(cm)], ref["aev"][:, cm], rtol=0, atol=1e-5)
+    dropped = np.setdiff1d(np.arange(ani.aev_length), cm)
+    assert np.all(ref["aev"][:, dropped] == 0)
+    _check(got, ref, inp.nlocal, "pruned")
+    ani.set_option("prune_absent_species", 0)
+    full = ani.compute(inp, ago=0)
+    assert ani.debug_view().aev_active_length == ani.aev_length
+    _check(full, ref, inp.nlocal, "full-width")
+    assert abs(full["energy"] - got["energy"]) < 1e-3
+    assert np.abs(full["force"] - got["force"]).max() < 1e-3
     ani.close()
