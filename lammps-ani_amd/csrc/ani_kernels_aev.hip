@@ -24,6 +24,9 @@
 // Transcendentals on the fast path are the hardware ones (v_exp_f32, v_log_f32, v_cos_f32, v_sin_f32, v_rcp_f32,
 // v_rsq_f32), as the reference's cuaev is built with -use_fast_math (src/ani_csrc/CMakeLists.txt:12-20).
 // Formulas and their derivatives are the ones restated in oracle/ani_oracle.c.
+#include <algorithm>
+#include <cstdlib>
+
 #include "ani_kernels.h"
 
 namespace ani {
@@ -124,13 +127,17 @@ __host__ __device__ constexpr int fast_wave_floats(int cap, bool bwd) {
   // backward adds r, fc, dx, dy, dz, j, gd[3] per radial neighbour
   return 6 * kMaxAng + kAevMax + kMaxBuckets * 8 + 16 + 48 + (bwd ? 9 * cap : 64 * 12 + 2 * cap);
 }
+// same with the AEV row sized for the columns actually in use (rowf floats, multiple of 64)
+__host__ __device__ constexpr int fast_wave_floats_row(int cap, bool bwd, int rowf) {
+  return fast_wave_floats(cap, bwd) - kAevMax + rowf;
+}
 
 template <int NA, int NZ>
-__device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd) {
+__device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int rowf) {
   FastLds L;
   float* p = base;
   L.ad = reinterpret_cast<float4*>(p); p += 4 * kMaxAng;
-  L.row = p; p += kAevMax;
+  L.row = p; p += rowf;
   if (!bwd) {
     L.pf2 = p; p += 64 * NA;
     L.pf1 = p; p += 64 * NZ;
@@ -331,7 +338,7 @@ template <int NA, int NZ>
 __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row, const Prefetched& pf,
                                                int lane) {
   constexpr int NR = 16, Q = 64 / NA;
-  for (int e = lane; e < kAevMax / 4; e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
+  for (int e = lane; e < (p.aev_stride >> 2); e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
   int nrad, nang;
   bool over;
   compact_sorted<false>(p, a, pf, lane, cap, L, nrad, nang, over);
@@ -466,10 +473,10 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
   }
 
 template <int NA, int NZ>
-__global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, AevArgs a, int cap) {
+__global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, AevArgs a, int cap, int rowf) {
   extern __shared__ float4 smem4[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, false), cap, false);
+  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, false, rowf), cap, false, rowf);
   ANI_PERSISTENT_LOOP(kWaves, (void)0, (forward_centre<NA, NZ>(p, a, cap, L, row, cur, lane)))
 }
 
@@ -479,7 +486,8 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   constexpr int NR = 16;
   const int4 info = pf.info;
 #pragma unroll
-  for (int c = 0; c < 4; c++) reinterpret_cast<float4*>(L.row)[lane + 64 * c] = grow[c];
+  for (int c = 0; c < 4; c++)
+    if (lane + 64 * c < (p.aev_stride >> 2)) reinterpret_cast<float4*>(L.row)[lane + 64 * c] = grow[c];
   int nrad, nang;
   bool over;
   compact_sorted<true>(p, a, pf, lane, cap, L, nrad, nang, over);
@@ -637,10 +645,10 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
 }
 
 template <int NA, int NZ>
-__global__ __launch_bounds__(64 * kWavesB) void aev_backward_fast(AevParams p, AevArgs a, int cap) {
+__global__ __launch_bounds__(64 * kWavesB) void aev_backward_fast(AevParams p, AevArgs a, int cap, int rowf) {
   extern __shared__ float4 smem4[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats(cap, true), cap, true);
+  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, true, rowf), cap, true, rowf);
   // dE/dAEV row of the current centre: 4 x 16 B per lane, issued BEFORE this iteration's prefetch loads so that the
   // wait for it (vmcnt counts in order) leaves the younger prefetches in flight
   float4 grow[4];
@@ -906,10 +914,18 @@ static int num_cus() {
   }();
   return n;
 }
+static const char* waves_env() { return "ANI_AEV_WAVES_PER_CU"; }  // experiment knob: cap on resident waves per CU
 // persistent grid of the fast path: as many workgroups as fit on the chip by LDS (at most 8 per CU)
-static int persistent_blocks(int nrows, int waves_per_block, size_t lds_bytes) {
-  int per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+template <typename K>
+static int persistent_blocks(K kernel, int nrows, int waves_per_block, size_t lds_bytes) {
+  // resident workgroups per CU by registers AND LDS; a grid larger than what is resident would run a second,
+  // mostly empty round of persistent workgroups
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * waves_per_block, lds_bytes) != hipSuccess || per_cu < 1)
+    per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
   if (per_cu > 8) per_cu = 8;
+  static const int forced = [] { const char* e = getenv(waves_env()); return e ? atoi(e) : 0; }();
+  if (forced > 0 && forced * waves_per_block / 2 >= 1) per_cu = std::min(per_cu, std::max(1, forced / waves_per_block));
   if (per_cu < 1) per_cu = 1;
   const int need = (nrows + waves_per_block - 1) / waves_per_block;
   const int fit = num_cus() * per_cu;
@@ -922,15 +938,16 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
   if (aev_fast_path(p, max_numneigh)) {
     int cap = (max_numneigh + 63) / 64 * 64;
     if (cap < 64) cap = 64;
-    const size_t lds = (size_t)fast_wave_floats(cap, false) * 4 * kWaves;
+    const int rowf = (p.aev_stride + 63) / 64 * 64;
+    const size_t lds = (size_t)fast_wave_floats_row(cap, false, rowf) * 4 * kWaves;
     if (fast_kind(p) == 1) {
       static bool once = (hipFuncSetAttribute((const void*)aev_forward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_forward_fast<8, 4>), dim3(persistent_blocks(a.nrows, kWaves, lds)), block, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_forward_fast<8, 4>), dim3(persistent_blocks(aev_forward_fast<8, 4>, a.nrows, kWaves, lds)), block, lds, st, p, a, cap, rowf);
     } else {
       static bool once = (hipFuncSetAttribute((const void*)aev_forward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_forward_fast<4, 8>), dim3(persistent_blocks(a.nrows, kWaves, lds)), block, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_forward_fast<4, 8>), dim3(persistent_blocks(aev_forward_fast<4, 8>, a.nrows, kWaves, lds)), block, lds, st, p, a, cap, rowf);
     }
   } else {
     hipLaunchKernelGGL(aev_forward_generic, grid, block, 0, st, p, a);
@@ -944,15 +961,16 @@ void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
   if (aev_fast_path(p, max_numneigh)) {
     int cap = (max_numneigh + 63) / 64 * 64;
     if (cap < 64) cap = 64;
-    const size_t lds = (size_t)fast_wave_floats(cap, true) * 4 * kWavesB;
+    const int rowf = (p.aev_stride + 63) / 64 * 64;
+    const size_t lds = (size_t)fast_wave_floats_row(cap, true, rowf) * 4 * kWavesB;
     if (fast_kind(p) == 1) {
       static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_backward_fast<8, 4>), dim3(persistent_blocks(a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_backward_fast<8, 4>), dim3(persistent_blocks(aev_backward_fast<8, 4>, a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap, rowf);
     } else {
       static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
-      hipLaunchKernelGGL((aev_backward_fast<4, 8>), dim3(persistent_blocks(a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap);
+      hipLaunchKernelGGL((aev_backward_fast<4, 8>), dim3(persistent_blocks(aev_backward_fast<4, 8>, a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap, rowf);
     }
   } else {
     hipLaunchKernelGGL(aev_backward_generic, grid, block, 0, st, p, a);
