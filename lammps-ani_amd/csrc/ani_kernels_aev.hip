@@ -53,14 +53,21 @@ constexpr float kLog2e = 1.4426950408889634f;
 
 // unordered pair index t -> (a, b), a < b < n, row-major over the strict upper triangle
 __device__ __forceinline__ void decode_pair(int t, int n, int& a, int& b) {
+  // closed form + one branch-free correction step each way; all quantities < 2^14, so 24-bit multiplies are exact
   const float fn = (float)(2 * n - 1);
-  int aa = (int)floorf((fn - sqrtf(fn * fn - 8.f * (float)t)) * 0.5f);
-  if (aa < 0) aa = 0;
-  if (aa > n - 2) aa = n - 2;
-  while (aa > 0 && aa * (2 * n - aa - 1) / 2 > t) aa--;
-  while ((aa + 1) * (2 * n - aa - 2) / 2 <= t) aa++;
+  int aa = (int)((fn - __builtin_amdgcn_sqrtf(fn * fn - 8.f * (float)t)) * 0.5f);
+  aa = max(0, min(aa, n - 2));
+  const int n2 = 2 * n - 1;
+  int s0 = __mul24(aa, n2 - aa) >> 1;              // first pair index of row aa
+  const bool dn = s0 > t;
+  aa -= dn ? 1 : 0;
+  s0 = dn ? (__mul24(aa, n2 - aa) >> 1) : s0;
+  const int s1 = __mul24(aa + 1, n2 - aa - 1) >> 1;  // first pair index of row aa + 1
+  const bool up = s1 <= t;
+  aa += up ? 1 : 0;
+  s0 = up ? s1 : s0;
   a = aa;
-  b = aa + 1 + (t - aa * (2 * n - aa - 1) / 2);
+  b = aa + 1 + (t - s0);
 }
 __device__ __forceinline__ int triu_index(int s1, int s2, int S) {
   const int lo = s1 < s2 ? s1 : s2, hi = s1 < s2 ? s2 : s1;
@@ -136,20 +143,21 @@ template <int NA, int NZ>
 __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int rowf) {
   FastLds L;
   float* p = base;
+  // fixed-size pieces first so that their offsets from the wave base are compile-time immediates
   L.ad = reinterpret_cast<float4*>(p); p += 4 * kMaxAng;
-  L.row = p; p += rowf;
-  if (!bwd) {
-    L.pf2 = p; p += 64 * NA;
-    L.pf1 = p; p += 64 * NZ;
-  } else {
-    L.pf2 = L.pf1 = nullptr;
-  }
   L.tb = reinterpret_cast<int*>(p); p += kMaxBuckets * 8;
   L.afc = p; p += kMaxAng;
   L.aidx = reinterpret_cast<int*>(p); p += kMaxAng;
   L.pb = reinterpret_cast<int*>(p); p += 16;
   L.rstart = reinterpret_cast<int*>(p); p += 24;
   L.astart = reinterpret_cast<int*>(p); p += 24;
+  if (!bwd) {
+    L.pf2 = p; p += 64 * NA;
+    L.pf1 = p; p += 64 * NZ;
+  } else {
+    L.pf2 = L.pf1 = nullptr;
+  }
+  L.row = p; p += rowf;
   L.rr = p; p += cap;
   L.rfc = p; p += cap;
   if (bwd) {
