@@ -79,11 +79,16 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # the reference maps local_rank % num_devices too (src/pair_ani.cpp:269-272)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("ANI_BENCH_BACKEND", "nccl")  # "gloo" = host-staged rehearsal of the multi-rank path on one GPU
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- workload ---------------------------------------------------------------------------------------
     model = mf.synthetic_model("ani2x", args.models, seed=2024)
@@ -92,7 +97,7 @@ def main():
     system = hx.spatial_sort(hx.water_box(args.atoms, seed=12345))  # LAMMPS sorts atoms spatially (atom_modify sort)
     grid = comm.grid_for(world)
     inp = hx.decompose(system, grid, rank, cutoff=5.1, skin=2.0)
-    ani = ani_hip.ANI(mpath, local_rank, -1, use_cuaev=(args.aev == "cuaev"), use_fullnbr=True, use_single=True)
+    ani = ani_hip.ANI(mpath, dev_index, -1, use_cuaev=(args.aev == "cuaev"), use_fullnbr=True, use_single=True)
     if args.dense_aev:
         ani.set_option("prune_absent_species", 0)
 
@@ -147,12 +152,13 @@ def main():
     if not np.isfinite(energy_local):
         raise SystemExit("non-finite energy: LDS neighbour capacity exceeded or numerical failure")
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # per-rank phase times and work, gathered for the roofline of the slowest rank
         stats = torch.tensor([phases["aev_fwd"], phases["mlp"], phases["aev_bwd"], phases["other"], inp.nlocal, inp.ntotal,
-                              inp.npairs], dtype=torch.float64, device=dev)
+                              inp.npairs], dtype=torch.float64, device=cdev)
         allstats = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(allstats, stats)
         allstats = torch.stack(allstats).cpu().numpy()

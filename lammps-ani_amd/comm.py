@@ -23,6 +23,9 @@ class GhostExchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.nlocal, self.nghost = inp.nlocal, inp.nghost
         self.device, self.dtype = device, dtype
+        # rehearsal mode: gloo cannot move device tensors, so messages are staged through the host (only used to run
+        # the multi-rank path on a single GPU; the real path is backend nccl = RCCL with device buffers)
+        self.host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda")
         order = np.argsort(inp.owner_rank, kind="stable")
         self.ghost_perm = torch.as_tensor(order.astype(np.int64), device=device)          # ghosts sorted by owner
         send_counts = np.bincount(inp.owner_rank, minlength=self.world).astype(np.int64)
@@ -30,17 +33,27 @@ class GhostExchange:
         lidx_sorted = torch.as_tensor(inp.owner_lidx[order].astype(np.int64), device=device)
         self.shift = torch.as_tensor((inp.shift[order] * np.asarray(box_len)[None, :]), device=device, dtype=dtype)
         if self.world > 1:
-            sc = torch.as_tensor(send_counts, device=device)
+            cdev = "cpu" if self.host_staged else device
+            sc = torch.as_tensor(send_counts, device=cdev)
             rc = torch.empty_like(sc)
             dist.all_to_all_single(rc, sc, group=group)
             self.recv_splits = rc.cpu().tolist()
-            self.recv_idx = torch.empty(int(sum(self.recv_splits)), dtype=torch.int64, device=device)
-            dist.all_to_all_single(self.recv_idx, lidx_sorted, self.recv_splits, self.send_splits, group=group)
+            ridx = torch.empty(int(sum(self.recv_splits)), dtype=torch.int64, device=cdev)
+            dist.all_to_all_single(ridx, lidx_sorted.to(cdev), self.recv_splits, self.send_splits, group=group)
+            self.recv_idx = ridx.to(device)
         else:
             self.recv_splits = self.send_splits
             self.recv_idx = lidx_sorted
         self._send = torch.empty((self.nghost, 3), dtype=dtype, device=device)
         self._recv = torch.empty((self.recv_idx.numel(), 3), dtype=dtype, device=device)
+
+    def _a2a(self, out, inp, out_splits, in_splits):
+        if self.host_staged:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     def reverse_add(self, f: torch.Tensor) -> None:
         """f: [ntotal,3]; adds every ghost's force into its owner's row (on whichever rank that is)."""
@@ -48,7 +61,7 @@ class GhostExchange:
             return
         torch.index_select(f[self.nlocal:], 0, self.ghost_perm, out=self._send)
         if self.world > 1:
-            dist.all_to_all_single(self._recv, self._send, self.recv_splits, self.send_splits, group=self.group)
+            self._a2a(self._recv, self._send, self.recv_splits, self.send_splits)
             f[: self.nlocal].index_add_(0, self.recv_idx, self._recv)
         else:
             f[: self.nlocal].index_add_(0, self.recv_idx, self._send)
@@ -59,7 +72,7 @@ class GhostExchange:
             return
         torch.index_select(x[: self.nlocal], 0, self.recv_idx, out=self._recv)
         if self.world > 1:
-            dist.all_to_all_single(self._send, self._recv, self.send_splits, self.recv_splits, group=self.group)
+            self._a2a(self._send, self._recv, self.send_splits, self.recv_splits)
         else:
             self._send.copy_(self._recv)
         x[self.nlocal:].index_copy_(0, self.ghost_perm, self._send + self.shift)
