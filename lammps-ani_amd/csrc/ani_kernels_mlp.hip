@@ -47,7 +47,7 @@ __device__ __forceinline__ float dcelu_from_h(float h, float inv_alpha) {
 #define ANI_GEMM_LB2 3  // workgroups per CU the 64-row variant is compiled for
 #endif
 template <int WM, int EPI>
-__global__ __launch_bounds__(256, (WM == 4 ? 2 : ANI_GEMM_LB2)) void gemm_grouped(GroupArgs G) {
+__global__ __launch_bounds__(256, (WM == 4 ? 2 : (WM == 2 ? ANI_GEMM_LB2 : 3))) void gemm_grouped(GroupArgs G) {
   constexpr int WN = 4 / WM;        // waves along N
   constexpr int R = 32 * WM;        // rows per workgroup
   constexpr int NTW = 8 / WN;       // max 32-column tiles per wave
@@ -290,8 +290,10 @@ static double makespan(const GemmArgs* probs, int nprob, int R, int ncu) {
     total += per_tile * tiles_m * nblocks * g.batch;
     biggest = per_tile > biggest ? per_tile : biggest;
   }
-  // greedy dispatch: every CU is busy until the work runs out, then at most one more tile
-  return total / ncu + biggest;
+  // greedy dispatch: every CU is busy until the work runs out, then at most one more tile.  Shorter tiles re-read the
+  // Bt slabs more often and have fewer MFMAs per staged byte: charged as a throughput factor (measured ballpark).
+  const double eff = R >= 128 ? 1.0 : (R >= 64 ? 0.98 : 0.75);
+  return total / (ncu * eff) + biggest;
 }
 
 void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st) {
@@ -304,7 +306,11 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
   for (int base = 0; base < nprob; base += kMaxProblems) {
     const int np = nprob - base < kMaxProblems ? nprob - base : kMaxProblems;
     int WM = forced;
-    if (WM != 2 && WM != 4) WM = makespan(probs + base, np, 64, ncu) < 0.97 * makespan(probs + base, np, 128, ncu) ? 2 : 4;
+    if (WM != 1 && WM != 2 && WM != 4) {
+      const double m32 = makespan(probs + base, np, 32, ncu), m64 = makespan(probs + base, np, 64, ncu),
+                   m128 = makespan(probs + base, np, 128, ncu);
+      WM = (m32 < m64 && m32 < m128) ? 1 : (m64 < m128 ? 2 : 4);
+    }
     const int R = 32 * WM;
     GroupArgs G;
     G.nprob = 0;
@@ -323,7 +329,8 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
     G.tile_start[G.nprob] = total;
     if (total == 0) continue;
     if (WM == 4) launch_wm<4>(G, epi, total, st);
-    else launch_wm<2>(G, epi, total, st);
+    else if (WM == 2) launch_wm<2>(G, epi, total, st);
+    else launch_wm<1>(G, epi, total, st);
   }
 }
 
