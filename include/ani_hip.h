@@ -45,7 +45,8 @@ typedef struct ani_handle ani_handle;
  *                   contributes with the cosine cutoff evaluated past Rcr.
  *                   Unlike the reference (models/lammps_ani.py:151-153,211) the virial is computed in both modes.
  *   use_fullnbr     1: ani_compute_full will be used, 0: ani_compute_half
- *   use_single      1: fp32 arithmetic on device (energy/virial sums in fp64); 0 (double) is not implemented yet
+ *   use_single      1: fp32 arithmetic on device (energy/virial sums in fp64) — the fast path (MFMA, tuned AEV kernels);
+ *                   0: fp64 throughout (the reference's `double`), a plain correctness path without MFMA
  * On failure *out is NULL and ani_last_error(NULL) holds the message.
  */
 int ani_create(const char* model_file, int local_rank, int use_num_models, int use_cuaev, int use_fullnbr,

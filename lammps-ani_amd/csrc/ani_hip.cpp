@@ -60,6 +60,9 @@ struct SpeciesNet {
   float* w_out = nullptr;   // [M][w(L-1)]
   float* b_out = nullptr;   // [M]
   std::vector<int> w;       // w[k] = round_up(d[k],4), k = 0..L-1 (w[0] = aev_stride)
+  // double-precision mirrors of the above (precision 'double' only)
+  std::vector<double*> W64, b64, WT64;
+  double *W0c64 = nullptr, *WT0c64 = nullptr, *w_out64 = nullptr, *b_out64 = nullptr;
 };
 
 }  // namespace
@@ -90,6 +93,8 @@ struct ani_handle {
   DevBuf<int4> row_info;
   DevBuf<double> x64, f64, ev, eatom, partial, virial_acc;
   DevBuf<float> aev, gaev, act, e_rows, fbuf;
+  DevBuf<double> aev64, gaev64, act64, e_rows64, fbuf64;  // precision 'double'
+  std::vector<std::vector<double*>> Hbuf64;
   std::vector<std::vector<float*>> Hbuf, Gbuf;  // [S][k] pointers into act
   // host staging for the host-pointer entry points
   std::vector<int> h_species32;
@@ -123,6 +128,17 @@ int upload(ani_handle* h, float** dst, const std::vector<float>& src) {
   return ANI_OK;
 }
 
+// precision 'double': the model file stores fp32 weights (exactly representable), so the fp64 copies are made on the
+// device from the fp32 uploads
+int mirror64(ani_handle* h, double** dst, const float* src, size_t n) {
+  if (h->use_single) return ANI_OK;
+  if (*dst) (void)hipFree(*dst);
+  HIP_TRY(h, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(double)));
+  launch_cvt_f32_f64(src, *dst, n, h->stream);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return ANI_OK;
+}
+
 int upload_model(ani_handle* h) {
   const HostModel& m = h->model;
   const int L = m.L, M = m.M;
@@ -136,6 +152,7 @@ int upload_model(ani_handle* h) {
     for (int k = 1; k < L; k++) n.w[k] = round_up(d[k], 4);
     if (d[L - 1] > 256) { h->err = "last hidden layer wider than 256 is not supported"; return ANI_ERR_MODEL; }
     n.W.assign(L - 1, nullptr); n.b.assign(L - 1, nullptr); n.WT.assign(L - 1, nullptr);
+    n.W64.assign(L - 1, nullptr); n.b64.assign(L - 1, nullptr); n.WT64.assign(L - 1, nullptr);
     for (int k = 0; k < L - 1; k++) {
       const int out = d[k + 1], in = d[k], kp = n.w[k];
       std::vector<float> W((size_t)M * out * kp, 0.f), b((size_t)M * out);
@@ -147,6 +164,8 @@ int upload_model(ani_handle* h) {
       }
       int rc = upload(h, &n.W[k], W); if (rc) return rc;
       rc = upload(h, &n.b[k], b); if (rc) return rc;
+      rc = mirror64(h, &n.W64[k], n.W[k], W.size()); if (rc) return rc;
+      rc = mirror64(h, &n.b64[k], n.b[k], b.size()); if (rc) return rc;
       // transposed copies for the backward products
       if (k == 0) {
         const int w1 = n.w[1];
@@ -155,6 +174,7 @@ int upload_model(ani_handle* h) {
           for (int o = 0; o < out; o++)
             for (int i = 0; i < in; i++) T[(size_t)i * M * w1 + (size_t)a * w1 + o] = m.W[a][s][0][(size_t)o * in + i];
         rc = upload(h, &n.WT[0], T); if (rc) return rc;
+        rc = mirror64(h, &n.WT64[0], n.WT[0], T.size()); if (rc) return rc;
       } else {
         const int wk1 = n.w[k + 1 < L ? k + 1 : k];  // K of the backward product through layer k = padded d[k+1]
         std::vector<float> T((size_t)M * in * wk1, 0.f);         // [M][d[k]][w(k+1)]
@@ -162,6 +182,7 @@ int upload_model(ani_handle* h) {
           for (int o = 0; o < out; o++)
             for (int i = 0; i < in; i++) T[((size_t)a * in + i) * wk1 + o] = m.W[a][s][k][(size_t)o * in + i];
         rc = upload(h, &n.WT[k], T); if (rc) return rc;
+        rc = mirror64(h, &n.WT64[k], n.WT[k], T.size()); if (rc) return rc;
       }
     }
     {  // output layer
@@ -173,6 +194,8 @@ int upload_model(ani_handle* h) {
       }
       int rc = upload(h, &n.w_out, w); if (rc) return rc;
       rc = upload(h, &n.b_out, b); if (rc) return rc;
+      rc = mirror64(h, &n.w_out64, n.w_out, w.size()); if (rc) return rc;
+      rc = mirror64(h, &n.b_out64, n.b_out, b.size()); if (rc) return rc;
     }
   }
   AevParams& p = h->ap;
@@ -201,7 +224,10 @@ int specialize(ani_handle* h, int mask) {
   for (auto& n : h->nets) {
     if (n.W0c) (void)hipFree(n.W0c);
     if (n.WT0c) (void)hipFree(n.WT0c);
+    if (n.W0c64) (void)hipFree(n.W0c64);
+    if (n.WT0c64) (void)hipFree(n.WT0c64);
     n.W0c = n.WT0c = nullptr;
+    n.W0c64 = n.WT0c64 = nullptr;
   }
   std::vector<int> act;
   for (int s = 0; s < m.S; s++) {
@@ -249,6 +275,8 @@ int specialize(ani_handle* h, int mask) {
         }
     int rc = upload(h, &n.W0c, W); if (rc) return rc;
     rc = upload(h, &n.WT0c, T); if (rc) return rc;
+    rc = mirror64(h, &n.W0c64, n.W0c, W.size()); if (rc) return rc;
+    rc = mirror64(h, &n.WT0c64, n.WT0c, T.size()); if (rc) return rc;
   }
   return ANI_OK;
 }
@@ -281,6 +309,25 @@ int rebuild(ani_handle* h, hipStream_t st) {
   launch_sort_jlist(h->species.p, h->nbr_off.p, h->numneigh.p, h->jraw.p, h->jlist.p, nlocal, m.S, st);
 
   const size_t stride = h->ap_run.aev_stride;
+  if (!h->use_single) {
+    HIP_TRY(h, h->aev64.reserve((size_t)std::max(h->nrows, 1) * stride));
+    HIP_TRY(h, h->gaev64.reserve((size_t)std::max(h->nrows, 1) * stride));
+    HIP_TRY(h, hipMemsetAsync(h->aev64.p, 0, (size_t)h->nrows * stride * sizeof(double), st));
+    HIP_TRY(h, h->e_rows64.reserve((size_t)m.M * std::max(h->nrows, 1)));
+    size_t need64 = 0;
+    for (int s = 0; s < m.S; s++)
+      for (int k = 1; k < m.L; k++) need64 += (size_t)round_up(h->count[s], kRowTile) * m.M * h->nets[s].w[k];
+    HIP_TRY(h, h->act64.reserve(std::max<size_t>(need64, 1)));
+    HIP_TRY(h, hipMemsetAsync(h->act64.p, 0, need64 * sizeof(double), st));
+    h->Hbuf64.assign(m.S, std::vector<double*>(m.L, nullptr));
+    size_t off64 = 0;
+    for (int s = 0; s < m.S; s++)
+      for (int k = 1; k < m.L; k++) {
+        h->Hbuf64[s][k] = h->act64.p + off64;
+        off64 += (size_t)round_up(h->count[s], kRowTile) * m.M * h->nets[s].w[k];
+      }
+    return ANI_OK;
+  }
   HIP_TRY(h, h->aev.reserve((size_t)std::max(h->nrows, 1) * stride));
   HIP_TRY(h, h->gaev.reserve((size_t)std::max(h->nrows, 1) * stride));
   HIP_TRY(h, hipMemsetAsync(h->aev.p, 0, (size_t)h->nrows * stride * sizeof(float), st));  // padding rows stay zero
@@ -389,9 +436,91 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
   launch_gemm_group(probs.data(), (int)probs.size(), EPI_PLAIN, st);
 }
 
+
+// precision 'double': same pipeline on the fp64 kernels (ani_kernels_f64.hip)
+int run_step64(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double* d_f, int f_accumulate, double* d_ev,
+               double* d_eatom, hipStream_t st) {
+  const HostModel& m = h->model;
+  const int L = m.L, M = m.M;
+  HIP_TRY(h, h->fbuf64.reserve((size_t)std::max(h->ntotal, 1) * 3));
+  HIP_TRY(h, h->virial_acc.reserve(9));
+  HIP_TRY(h, h->err_flag.reserve(1, true));
+  HIP_TRY(h, hipMemsetAsync(h->fbuf64.p, 0, sizeof(double) * 3 * (size_t)h->ntotal, st));
+  HIP_TRY(h, hipMemsetAsync(h->virial_acc.p, 0, sizeof(double) * 9, st));
+  HIP_TRY(h, hipMemsetAsync(h->e_rows64.p, 0, sizeof(double) * (size_t)M * std::max(h->nrows, 1), st));
+  Aev64Params p{};
+  const AevParams& r = h->ap_run;
+  p.S = r.S; p.nR = r.nR; p.nA = r.nA; p.nZ = r.nZ; p.radial_len = r.radial_len; p.aev_len = r.aev_len; p.aev_stride = r.aev_stride;
+  p.compat = r.compat;
+  p.Rcr = m.Rcr; p.Rca = m.Rca; p.EtaR = m.EtaR; p.EtaA = m.EtaA; p.Zeta = m.Zeta;
+  for (int k = 0; k < m.nR; k++) p.ShfR[k] = m.ShfR[k];
+  for (int k = 0; k < m.nA; k++) p.ShfA[k] = m.ShfA[k];
+  for (int k = 0; k < m.nZ; k++) { p.cosZ[k] = cos(m.ShfZ[k]); p.sinZ[k] = sin(m.ShfZ[k]); }
+  Aev64Args a{};
+  a.x = d_x; a.species = h->species.p; a.cmap = h->cmap; a.jlist = h->jlist.p; a.row_info = h->row_info.p; a.nrows = h->nrows;
+  a.aev = h->aev64.p; a.gaev = h->gaev64.p; a.fbuf = h->fbuf64.p; a.virial = vflag ? h->virial_acc.p : nullptr;
+  a.err_flag = h->err_flag.p;
+  launch_aev64_forward(p, a, st);
+  const int ka = r.aev_stride;
+  for (int s = 0; s < m.S; s++) {
+    if (h->count[s] == 0) continue;
+    const SpeciesNet& n = h->nets[s];
+    const std::vector<int>& d = m.dims[s];
+    const int rows = round_up(h->count[s], kRowTile), r0 = h->row_start[s];
+    auto base = [&]() {
+      Gemm64Args g{};
+      g.rows = rows; g.batch = M; g.alpha = m.alpha; g.scale = 1.0 / M; g.centre_of_row = h->centre_of_row.p + r0;
+      return g;
+    };
+    for (int k = 0; k <= L - 2; k++) {
+      Gemm64Args g = base();
+      if (k == 0) {
+        g.A = h->aev64.p + (size_t)r0 * ka; g.lda = ka; g.sA = 0; g.K = ka;
+        g.Bt = n.W0c64 ? n.W0c64 : n.W64[0]; g.ldb = ka; g.sB = (long long)d[1] * ka;
+      } else {
+        g.A = h->Hbuf64[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k]; g.K = n.w[k];
+        g.Bt = n.W64[k]; g.ldb = n.w[k]; g.sB = (long long)d[k + 1] * n.w[k];
+      }
+      g.N = d[k + 1]; g.bias = n.b64[k]; g.sBias = d[k + 1];
+      g.C = h->Hbuf64[s][k + 1]; g.ldc = M * n.w[k + 1]; g.sC = n.w[k + 1];
+      if (k == L - 2) {
+        g.aux = n.w_out64; g.sAux = n.w[L - 1]; g.bias_last = n.b_out64;
+        g.e_out = h->e_rows64.p + r0; g.sE = h->nrows;
+      }
+      launch_gemm64(g, k == L - 2 ? EPI_LAST : EPI_CELU, st);
+    }
+    for (int k = L - 1; k >= 2; k--) {
+      Gemm64Args g = base();
+      g.A = h->Hbuf64[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k]; g.K = n.w[k];
+      g.Bt = n.WT64[k - 1]; g.ldb = n.w[k]; g.sB = (long long)d[k - 1] * n.w[k];
+      g.N = d[k - 1];
+      g.aux = h->Hbuf64[s][k - 1]; g.ldaux = M * n.w[k - 1]; g.sAux = n.w[k - 1];
+      g.C = h->Hbuf64[s][k - 1]; g.ldc = M * n.w[k - 1]; g.sC = n.w[k - 1];
+      launch_gemm64(g, EPI_BWD, st);
+    }
+    {
+      Gemm64Args g = base();
+      g.batch = 1;
+      g.A = h->Hbuf64[s][1]; g.lda = M * n.w[1]; g.K = M * n.w[1];
+      g.Bt = n.WT0c64 ? n.WT0c64 : n.WT64[0]; g.ldb = M * n.w[1];
+      g.N = r.aev_len;
+      g.C = h->gaev64.p + (size_t)r0 * ka; g.ldc = ka;
+      launch_gemm64(g, EPI_PLAIN, st);
+    }
+  }
+  launch_aev64_backward(p, a, st);
+  Sae64 sae{};
+  for (int s = 0; s < m.S; s++) sae.v[s] = m.sae[s];
+  launch_finish64(h->e_rows64.p, M, h->nrows, h->centre_of_row.p, h->ilist.p, h->species.p, sae, h->fbuf64.p, h->ntotal,
+                  vflag ? h->virial_acc.p : nullptr, d_f, f_accumulate, d_ev, eflag_atom ? d_eatom : nullptr, h->err_flag.p, st);
+  HIP_TRY(h, hipGetLastError());
+  return ANI_OK;
+}
+
 // the per-step pipeline on device-resident inputs; the list of this epoch is already in the handle's buffers
 int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double* d_f, int f_accumulate, double* d_ev,
              double* d_eatom, hipStream_t st) {
+  if (!h->use_single) return run_step64(h, d_x, eflag_atom, vflag, d_f, f_accumulate, d_ev, d_eatom, st);
   const HostModel& m = h->model;
   HIP_TRY(h, h->xyzs.reserve(h->ntotal));
   HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 3));
@@ -488,15 +617,11 @@ int ani_create(const char* model_file, int local_rank, int use_num_models, int u
     g_create_error = "device 'cpu' (local_rank = -1) is not available: libani_hip is the HIP/gfx950 path only and has no host fallback";
     return ANI_ERR_ARG;
   }
-  if (!use_single) {
-    g_create_error = "precision 'double' is not implemented in libani_hip yet (use 'single')";
-    return ANI_ERR_ARG;
-  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device visible"; return ANI_ERR_DEVICE; }
   ani_handle* h = new ani_handle;
   h->device = local_rank % ndev;  // src/pair_ani.cpp:269-272
-  h->use_cuaev = use_cuaev != 0; h->use_fullnbr = use_fullnbr != 0; h->use_single = true;
+  h->use_cuaev = use_cuaev != 0; h->use_fullnbr = use_fullnbr != 0; h->use_single = use_single != 0;
   std::string e = load_model(model_file, use_num_models, h->model);
   if (!e.empty()) { g_create_error = e; delete h; return ANI_ERR_MODEL; }
   if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -507,8 +632,8 @@ int ani_create(const char* model_file, int local_rank, int use_num_models, int u
   int rc = upload_model(h);
   if (rc != ANI_OK) { g_create_error = h->err; ani_destroy(h); return rc; }
   // banner, same fields as src/ani_csrc/ani.cpp:88-92
-  printf("Successfully loaded the model \nfile: '%s' \ndevice: hip:%d \ndtype: float (FP32) \nnbrlist: %s \nani_aev: %s \nuse_num_models: %d/%d\n\n",
-         model_file, h->device, h->use_fullnbr ? "full" : "half", h->use_cuaev ? "cuaev" : "pyaev", h->model.M, h->model.M_file);
+  printf("Successfully loaded the model \nfile: '%s' \ndevice: hip:%d \ndtype: %s \nnbrlist: %s \nani_aev: %s \nuse_num_models: %d/%d\n\n",
+         model_file, h->device, h->use_single ? "float (FP32)" : "double (FP64)", h->use_fullnbr ? "full" : "half", h->use_cuaev ? "cuaev" : "pyaev", h->model.M, h->model.M_file);
   fflush(stdout);
   *out = h;
   return ANI_OK;
@@ -526,11 +651,18 @@ void ani_destroy(ani_handle* h) {
     if (n.WT0c) (void)hipFree(n.WT0c);
     if (n.w_out) (void)hipFree(n.w_out);
     if (n.b_out) (void)hipFree(n.b_out);
+    for (double* p : n.W64) if (p) (void)hipFree(p);
+    for (double* p : n.b64) if (p) (void)hipFree(p);
+    for (double* p : n.WT64) if (p) (void)hipFree(p);
+    if (n.W0c64) (void)hipFree(n.W0c64);
+    if (n.WT0c64) (void)hipFree(n.WT0c64);
+    if (n.w_out64) (void)hipFree(n.w_out64);
+    if (n.b_out64) (void)hipFree(n.b_out64);
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
   h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
   h->xyzs.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release();
-  h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->e_rows.release(); h->fbuf.release();
+  h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();
   for (auto& e : h->evt_pool) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

@@ -96,4 +96,39 @@ struct FinishArgs {
 };
 void launch_finish(const FinishArgs& a, hipStream_t st);
 
+// ---- double precision path (ani_kernels_f64.hip) ------------------------------------------------------------
+struct Aev64Params {
+  int S, nR, nA, nZ, radial_len, aev_len, aev_stride, compat;
+  double Rcr, Rca, EtaR, EtaA, Zeta;
+  double ShfR[kMaxShfR], ShfA[kMaxShfA], cosZ[kMaxShfZ], sinZ[kMaxShfZ];
+};
+struct Aev64Args {
+  const double* x;         // [ntotal*3]
+  const int* species;      // [ntotal] model species
+  SpeciesMap cmap;         // species -> index among the species present
+  const int* jlist;
+  const int4* row_info;
+  int nrows;
+  double* aev;
+  const double* gaev;
+  double* fbuf;            // [ntotal*3] Hartree/Angstrom
+  double* virial;          // [9] or NULL
+  int* err_flag;
+};
+struct Gemm64Args {
+  const double* A; const double* Bt; double* C; const double* bias; const double* aux; const double* bias_last; double* e_out;
+  const int* centre_of_row;
+  long long sA, sB, sC, sBias, sAux, sE;
+  int lda, ldb, ldc, ldaux, rows, N, K, batch;
+  double scale, alpha;
+};
+struct Sae64 { double v[kMaxSpecies]; };
+void launch_cvt_f32_f64(const float* src, double* dst, size_t n, hipStream_t st);
+void launch_aev64_forward(const Aev64Params& p, const Aev64Args& a, hipStream_t st);
+void launch_aev64_backward(const Aev64Params& p, const Aev64Args& a, hipStream_t st);
+void launch_gemm64(const Gemm64Args& g, Epilogue epi, hipStream_t st);
+void launch_finish64(const double* e_rows, int M, int nrows, const int* centre_of_row, const int* ilist, const int* species,
+                     const Sae64& sae, const double* fbuf, int ntotal, const double* vir, double* f_out, int accumulate, double* ev,
+                     double* eatom, const int* err_flag, hipStream_t st);
+
 }  // namespace ani

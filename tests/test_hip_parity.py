@@ -119,12 +119,10 @@ def test_hip_water_1500_against_oracle(model_cache, hip):
     ani.close()
 
 
-def test_hip_refuses_cpu_and_double(model_cache, hip):
+def test_hip_refuses_cpu(model_cache, hip):
     p = model_cache("tiny", 2, 5)
     with pytest.raises(hip.AniError, match="cpu"):
         hip.ANI(p, -1)
-    with pytest.raises(hip.AniError, match="double"):
-        hip.ANI(p, 0, use_single=False)
     with pytest.raises(hip.AniError, match="cannot open"):
         hip.ANI("/nonexistent.anim", 0)
 
@@ -211,4 +209,23 @@ def test_hip_prunes_columns_of_absent_species(model_cache, hip):
     _check(full, ref, inp.nlocal, "full-width")
     assert abs(full["energy"] - got["energy"]) < 1e-3
     assert np.abs(full["force"] - got["force"]).max() < 1e-3
+    ani.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("mode", ["strict", "compat"])
+@pytest.mark.parametrize("half", [False, True], ids=["full", "half"])
+def test_hip_double_precision_matches_golden(case, mode, half, model_cache, hip):
+    """precision 'double' (pair_style ... single|double, src/pair_ani.cpp:326-337): fp64 kernels against the fp64
+    fixtures at the reference's own fp64 bars — 1e-8 on forces (src/ani_csrc/test_model.cpp:164), 9e-9 relative on the
+    energy (yaml epsilon)."""
+    g = load_golden(case)
+    inp = golden_input(g, half=half)
+    ani = hip.ANI(golden_model_path(g, model_cache), 0, -1, use_cuaev=(mode == "strict"), use_fullnbr=not half, use_single=False)
+    for ago in (0, 1):
+        got = ani.compute(inp, ago=ago)
+        assert abs(got["energy"] - float(g[f"{mode}_energy"])) < 9e-9 * abs(float(g[f"{mode}_energy"]))
+        np.testing.assert_allclose(got["force"], g[f"{mode}_force"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(got["eatom"], g[f"{mode}_eatom"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(got["virial"], g[f"{mode}_virial"], rtol=0, atol=1e-6)
     ani.close()

@@ -114,6 +114,21 @@ def test_adapter_requires_newton_pair_off(mock, model_cache):
     h = mock.mock_create(b"real", 1)
     rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", "full"], ntypes=3)
     assert rc == 1 and "newton pair off" in err
+
+
+@pytest.mark.gpu
+def test_adapter_double_precision(mock, model_cache):
+    """`... half double`, the configuration of the reference's fp64 yaml files."""
+    g = load_golden("water30_pbc_ani2x_m8")
+    inp = golden_input(g, half=True)
+    p = golden_model_path(g, model_cache)
     h = mock.mock_create(b"real", 0)
-    rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", "full", "double"], ntypes=3)
-    assert rc == 1 and "double" in err
+    rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "pyaev", "half", "double"])
+    assert rc == 0, err
+    f, e, v, ea = _run(mock, h, inp, 0)
+    ref_f = g["compat_force"]
+    folded = ref_f[: inp.nlocal].copy()
+    np.add.at(folded, inp.owner_lidx, ref_f[inp.nlocal:])
+    assert abs(e - float(g["compat_energy"])) < 9e-9 * abs(float(g["compat_energy"]))
+    np.testing.assert_allclose(f[: inp.nlocal], folded, rtol=0, atol=1e-8)
+    mock.mock_destroy(h)
