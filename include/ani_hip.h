@@ -110,6 +110,24 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
                             int64_t npairs, const int* d_ilist, const int* d_jlist, const int* d_numneigh, int ago,
                             int eflag_atom, int vflag, double* d_f, double* d_ev, double* d_eatom, void* stream);
 
+/*
+ * Device-side neighbour list: does on the device what LAMMPS core does on the host for
+ * `neighbor <skin> bin` + the full-list request of src/pair_ani.cpp:219-223, and installs the result in the handle
+ * as this epoch's list.  After it, call ani_compute_full_device with ago != 0 and NULL list pointers until the next
+ * rebuild.
+ *   d_species[ntotal], d_x[ntotal*3]   owned atoms first, then ghosts (ghosts carry the periodic images)
+ *   cutneigh                           force cutoff + skin (7.1 A for the reference's inputs)
+ *   lo[3], hi[3]                       host doubles: a box around the atoms (sub-domain widened by the ghost cutoff);
+ *                                      atoms outside it are still handled correctly (clamped into the edge cells)
+ *   out_npairs                         pairs in the list (may be NULL)
+ * Centres are the atoms 0..nlocal-1 in order (ilist = identity).  Synchronises `stream` once (the pair count sizes
+ * the list); list order is deterministic (by cell, then atom index).
+ */
+int ani_build_list_device(ani_handle* h, int ntotal, int nlocal, const int* d_species, const double* d_x, double cutneigh,
+                          const double* lo, const double* hi, int64_t* out_npairs, void* stream);
+/* device pointers of the installed list (tests): numneigh[nlocal], its exclusive scan [nlocal+1], jlist[npairs] */
+int ani_debug_list(ani_handle* h, const int** d_numneigh, const int** d_nbr_off, const int** d_jlist);
+
 /* last-step diagnostics for tests / roofline accounting (device pointers valid until the next compute or destroy) */
 typedef struct {
   int nlocal, ntotal, nrows;       /* nrows: species-bucketed AEV rows incl. padding */

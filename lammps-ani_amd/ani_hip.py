@@ -68,6 +68,9 @@ def lib():
         L.ani_compute_full_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ani_build_list_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
+                                            C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+        L.ani_debug_list.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3
         L.ani_debug_get.argtypes = [C.c_void_p, C.POINTER(DebugView)]
         L.ani_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.ani_debug_colmap.argtypes = [C.c_void_p, C.c_void_p]
@@ -139,6 +142,24 @@ class ANI:
         rc = self._lib.ani_compute_full_device(self._h, ntotal, nlocal, d_species, d_x, npairs, d_ilist, d_jlist,
                                                d_numneigh, ago, int(eflag_atom), int(vflag), d_f, d_ev, d_eatom, stream)
         self._check(rc)
+
+    def build_list_device(self, ntotal, nlocal, d_species, d_x, cutneigh, lo, hi, stream=None) -> int:
+        """Device-side full neighbour list (ani_build_list_device); returns the pair count.  Follow with
+        ``compute_device(..., ago=1)`` and null list pointers."""
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        n = C.c_int64()
+        self._check(self._lib.ani_build_list_device(self._h, ntotal, nlocal, d_species, d_x, float(cutneigh),
+                                                    lo.ctypes.data, hi.ctypes.data, C.byref(n), stream))
+        return n.value
+
+    def debug_list(self, nlocal: int):
+        """(numneigh[nlocal], jlist[npairs]) of the list installed in the handle, as host arrays."""
+        pn, po, pj = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self._lib.ani_debug_list(self._h, C.byref(pn), C.byref(po), C.byref(pj)))
+        nn = self.debug_read(pn, (nlocal,), np.int32)
+        jl = self.debug_read(pj, (int(nn.sum()),), np.int32)
+        return nn, jl
 
     def debug_view(self) -> DebugView:
         v = DebugView()

@@ -47,6 +47,18 @@ class GhostExchange:
         self._send = torch.empty((self.nghost, 3), dtype=dtype, device=device)
         self._recv = torch.empty((self.recv_idx.numel(), 3), dtype=dtype, device=device)
 
+    def reset_single(self, owner_idx: torch.Tensor, shift: torch.Tensor) -> None:
+        """Single-rank periodic case: replace the ghost set (what LAMMPS' Comm::borders() does at re-neighbouring).
+        owner_idx[nghost]: owned atom each ghost images; shift[nghost,3]: its image displacement."""
+        assert self.world == 1
+        self.nghost = int(owner_idx.numel())
+        self.ghost_perm = torch.arange(self.nghost, device=self.device)
+        self.recv_idx = owner_idx
+        self.shift = shift.to(self.dtype)
+        self.send_splits = self.recv_splits = [self.nghost]
+        self._send = torch.empty((self.nghost, 3), dtype=self.dtype, device=self.device)
+        self._recv = torch.empty((self.nghost, 3), dtype=self.dtype, device=self.device)
+
     def _a2a(self, out, inp, out_splits, in_splits):
         if self.host_staged:
             o = torch.empty(out.shape, dtype=out.dtype)

@@ -94,6 +94,8 @@ struct ani_handle {
   DevBuf<double> x64, f64, ev, eatom, partial, virial_acc;
   DevBuf<float> aev, gaev, act, e_rows, fbuf;
   DevBuf<double> aev64, gaev64, act64, e_rows64, fbuf64;  // precision 'double'
+  DevBuf<int> nb_cell_id, nb_cell_count, nb_cell_start, nb_cursor, nb_order;  // device-side list build (row f1)
+  DevBuf<double> nb_xs;
   std::vector<std::vector<double*>> Hbuf64;
   std::vector<std::vector<float*>> Hbuf, Gbuf;  // [S][k] pointers into act
   // host staging for the host-pointer entry points
@@ -662,6 +664,7 @@ void ani_destroy(ani_handle* h) {
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
   h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
   h->xyzs.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release();
+  h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();
   for (auto& e : h->evt_pool) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -702,6 +705,59 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
     h->have_list = true;
   }
   return run_step(h, d_x, eflag_atom, vflag, d_f, /*accumulate=*/1, d_ev, d_eatom, st);
+}
+
+int ani_build_list_device(ani_handle* h, int ntotal, int nlocal, const int* d_species, const double* d_x, double cutneigh,
+                          const double* lo, const double* hi, int64_t* out_npairs, void* stream) {
+  int rc = check_args(h, ntotal, nlocal, 0, 0);
+  if (rc) return rc;
+  if (!d_species || !d_x || !lo || !hi) { h->err = "null pointer"; return ANI_ERR_ARG; }
+  if (!(cutneigh >= h->model.Rcr)) { h->err = "cutneigh must be at least the model's radial cutoff"; return ANI_ERR_ARG; }
+  if (!h->use_fullnbr) { h->err = "ani_build_list_device builds a full list; the handle was created for half lists"; return ANI_ERR_ARG; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  NbrGrid g;
+  long long ncell = 1;
+  for (int k = 0; k < 3; k++) {
+    const double len = hi[k] - lo[k];
+    if (!(len > 0)) { h->err = "empty bounding box"; return ANI_ERR_ARG; }
+    int nc = (int)(len / cutneigh);
+    nc = std::max(1, std::min(nc, 1024));
+    g.lo[k] = lo[k]; g.inv[k] = nc / len; g.nc[k] = nc;
+    ncell *= nc;
+  }
+  if (ncell > (1LL << 26)) { h->err = "bounding box too large for the cell grid"; return ANI_ERR_ARG; }
+  g.ncell = (int)ncell;
+  h->have_list = false;
+  h->ntotal = ntotal; h->nlocal = nlocal;
+  HIP_TRY(h, h->nb_cell_id.reserve(ntotal));
+  HIP_TRY(h, h->nb_cell_count.reserve((size_t)g.ncell + 1));
+  HIP_TRY(h, h->nb_cell_start.reserve((size_t)g.ncell + 1));
+  HIP_TRY(h, h->nb_cursor.reserve(g.ncell));
+  HIP_TRY(h, h->nb_order.reserve(ntotal));
+  HIP_TRY(h, h->nb_xs.reserve((size_t)3 * ntotal));
+  HIP_TRY(h, h->species.reserve(ntotal));
+  HIP_TRY(h, h->ilist.reserve(nlocal));
+  HIP_TRY(h, h->numneigh.reserve(nlocal));
+  HIP_TRY(h, h->nbr_off.reserve((size_t)nlocal + 1));
+  NbrScratch s{h->nb_cell_id.p, h->nb_cell_count.p, h->nb_cell_start.p, h->nb_cursor.p, h->nb_order.p, h->nb_xs.p};
+  HIP_TRY(h, hipMemcpyAsync(h->species.p, d_species, sizeof(int) * (size_t)ntotal, hipMemcpyDeviceToDevice, st));
+  launch_nbr_bin(d_x, ntotal, g, s, st);
+  launch_nbr_count(nlocal, ntotal, g, s, cutneigh, h->numneigh.p, h->nbr_off.p, st);
+  int total = 0;
+  HIP_TRY(h, hipMemcpyAsync(&total, h->nbr_off.p + nlocal, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));  // the pair count sizes the list buffers (rebuild steps only)
+  if (total < 0) { h->err = "more than 2^31 neighbour pairs per rank is not supported"; return ANI_ERR_ARG; }
+  h->npairs = total;
+  HIP_TRY(h, h->jlist.reserve(total));
+  HIP_TRY(h, h->jraw.reserve(total));
+  launch_nbr_fill(nlocal, ntotal, g, s, cutneigh, h->nbr_off.p, h->jraw.p, h->ilist.p, st);
+  HIP_TRY(h, hipGetLastError());
+  rc = rebuild(h, st);
+  if (rc) return rc;
+  h->have_list = true;
+  if (out_npairs) *out_npairs = total;
+  return ANI_OK;
 }
 
 int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates, int64_t npairs,
@@ -783,6 +839,14 @@ int ani_debug_get(ani_handle* h, ani_debug_view* out) {
   out->d_aev = h->aev.p; out->d_gaev = h->gaev.p; out->d_row_of_centre = h->row_of_centre.p;
   out->aev_stride = h->ap_run.aev_stride; out->aev_active_length = h->ap_run.aev_len;
   for (int s = 0; s < kMaxSpecies && s < 16; s++) out->species_count[s] = h->count[s];
+  return ANI_OK;
+}
+
+int ani_debug_list(ani_handle* h, const int** d_numneigh, const int** d_nbr_off, const int** d_jlist) {
+  if (!h || !h->have_list) return ANI_ERR_ARG;
+  if (d_numneigh) *d_numneigh = h->numneigh.p;
+  if (d_nbr_off) *d_nbr_off = h->nbr_off.p;
+  if (d_jlist) *d_jlist = h->jraw.p;
   return ANI_OK;
 }
 

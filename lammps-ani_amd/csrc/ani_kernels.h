@@ -76,6 +76,27 @@ bool aev_fast_path(const AevParams& p, int max_numneigh);
 void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_numneigh, const int* d_jin, int* d_jout,
                        int nlocal, int S, hipStream_t st);
 
+// device-side neighbour list (ani_kernels_nbr.hip): cells of edge >= cutneigh over [lo, hi)
+struct NbrGrid {
+  double lo[3], inv[3];  // inv = nc / (hi - lo)
+  int nc[3], ncell;
+};
+struct NbrScratch {
+  int* cell_id;     // [ntotal]
+  int* cell_count;  // [ncell+1]
+  int* cell_start;  // [ncell+1]
+  int* cursor;      // [ncell]
+  int* order;       // [ntotal] atoms sorted by cell
+  double* xs;       // [ntotal*3] positions in that order
+};
+void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrScratch& s, hipStream_t st);
+// numneigh[nlocal] and its exclusive scan nbr_off[nlocal+1]
+void launch_nbr_count(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int* d_numneigh,
+                      int* d_nbr_off, hipStream_t st);
+// jlist (flattened in atom order) and the identity ilist
+void launch_nbr_fill(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, const int* d_nbr_off,
+                     int* d_jlist, int* d_ilist, hipStream_t st);
+
 // energy reduction (+ self energies), per-centre energies, force conversion
 struct FinishArgs {
   const float* e_rows;   // [M][nrows_ld] per-member row energies (already scaled by 1/M)

@@ -2,6 +2,7 @@
 // preparation (what src/ani_csrc/ani.cpp:213-229 and models/lammps_ani.py:156-166 do with torch ops every
 // rebuild / every step), and the final reductions / unit conversion (src/ani_csrc/ani.cpp:246-262).
 #include "ani_kernels.h"
+#include "ani_scan.h"
 
 namespace ani {
 
@@ -22,29 +23,6 @@ void launch_pack(const double* d_x, const int* d_species, int ntotal, const Spec
 }
 
 // ---- rebuild-time preparation ------------------------------------------------------------------------
-// block-wide exclusive scan of one int per thread (1024 threads = 16 waves); returns the block total
-__device__ __forceinline__ int block_exclusive_scan(int v, int& total, int* wave_sums) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
-  }
-  __syncthreads();
-  if (lane == 63) wave_sums[wave] = incl;
-  __syncthreads();
-  int base = 0, tot = 0;
-  const int nw = blockDim.x >> 6;
-  for (int w = 0; w < nw; w++) {
-    const int s = wave_sums[w];
-    if (w < wave) base += s;
-    tot += s;
-  }
-  total = tot;
-  return base + incl - v;
-}
-
 // block 0: exclusive scan of numneigh; blocks 1..S: stable rank of the centres of species s-1.
 // The species counts are needed before ranks can be turned into rows, hence two kernels.
 __global__ __launch_bounds__(1024) void prepare_count_kernel(const int* __restrict__ species, const int* __restrict__ ilist,

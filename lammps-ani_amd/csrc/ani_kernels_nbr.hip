@@ -1,0 +1,159 @@
+// ani_kernels_nbr.hip — device-side construction of the LAMMPS-style full neighbour list.
+//
+// What LAMMPS core does on the host for `neighbor 2.0 bin` + a full list request (src/pair_ani.cpp:219-223 asks for
+// NeighConst::REQ_FULL): bin the nlocal + nghost atoms of the rank into cells no smaller than the neighbour cutoff
+// (force cutoff + skin), then for every owned atom collect the atoms of the 27 surrounding cells closer than that
+// cutoff.  Ghost atoms carry the periodic images, so there is no wrapping here, exactly as in LAMMPS' binned builds.
+//
+// Layout: atoms are counting-sorted by cell (`order`, ascending atom index inside a cell, so the list is
+// deterministic) and their positions copied in that order (`xs`), which makes the three x-adjacent cells of a
+// (y,z) column one contiguous range.  One thread per atom in sorted order: neighbouring lanes walk the same ranges,
+// so the loads are broadcasts out of L1/L2.  Two passes (count, fill) around one scan; the list is HBM-bound
+// integer work (4 B per pair written once).
+#include "ani_kernels.h"
+#include "ani_scan.h"
+
+namespace ani {
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+__device__ __forceinline__ void cell_coords(const NbrGrid& g, double x, double y, double z, int& cx, int& cy, int& cz) {
+  // atoms outside [lo,hi) are clamped into the boundary cells: two atoms closer than one cell edge still land in
+  // cells whose (clamped) indices differ by at most one, so the 27-cell search stays exact
+  cx = clampi((int)floor((x - g.lo[0]) * g.inv[0]), g.nc[0] - 1);
+  cy = clampi((int)floor((y - g.lo[1]) * g.inv[1]), g.nc[1] - 1);
+  cz = clampi((int)floor((z - g.lo[2]) * g.inv[2]), g.nc[2] - 1);
+}
+
+__global__ void nbr_bin_count_kernel(const double* __restrict__ x, int ntotal, NbrGrid g, int* __restrict__ cell_id,
+                                     int* __restrict__ cell_count) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= ntotal) return;
+  int cx, cy, cz;
+  cell_coords(g, x[3 * a], x[3 * a + 1], x[3 * a + 2], cx, cy, cz);
+  const int c = (cz * g.nc[1] + cy) * g.nc[0] + cx;
+  cell_id[a] = c;
+  atomicAdd(&cell_count[c], 1);
+}
+
+// out[0..n] = exclusive scan of in[0..n), single block
+__global__ __launch_bounds__(1024) void nbr_scan_kernel(const int* __restrict__ in, int* __restrict__ out, int n) {
+  __shared__ int wave_sums[16];
+  int carry = 0;
+  for (int base = 0; base < n; base += blockDim.x) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? in[i] : 0;
+    int total;
+    const int ex = block_exclusive_scan(v, total, wave_sums);
+    if (i < n) out[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) out[n] = carry;
+}
+
+__global__ void nbr_bin_fill_kernel(const int* __restrict__ cell_id, const int* __restrict__ cell_start,
+                                    int* __restrict__ cursor, int* __restrict__ order, int ntotal) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= ntotal) return;
+  const int c = cell_id[a];
+  order[cell_start[c] + atomicAdd(&cursor[c], 1)] = a;
+}
+
+// ascending atom index inside every cell (the atomics above fill in arbitrary order)
+__global__ void nbr_bin_sort_kernel(const int* __restrict__ cell_start, int* __restrict__ order, int ncell) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int beg = cell_start[c], end = cell_start[c + 1];
+  for (int p = beg + 1; p < end; p++) {
+    const int v = order[p];
+    int q = p - 1;
+    while (q >= beg && order[q] > v) { order[q + 1] = order[q]; q--; }
+    order[q + 1] = v;
+  }
+}
+
+__global__ void nbr_gather_kernel(const double* __restrict__ x, const int* __restrict__ order, int ntotal,
+                                  double* __restrict__ xs) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ntotal) return;
+  const int a = order[p];
+  xs[3 * p] = x[3 * a]; xs[3 * p + 1] = x[3 * a + 1]; xs[3 * p + 2] = x[3 * a + 2];
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void nbr_search_kernel(const double* __restrict__ xs, const int* __restrict__ order,
+                                                          const int* __restrict__ cell_start, NbrGrid g, int nlocal,
+                                                          int ntotal, double cut2, int* __restrict__ numneigh,
+                                                          const int* __restrict__ nbr_off, int* __restrict__ jlist) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ntotal) return;
+  const int i = order[p];
+  if (i >= nlocal) return;  // ghosts are neighbours only
+  const double xi = xs[3 * p], yi = xs[3 * p + 1], zi = xs[3 * p + 2];
+  int cx, cy, cz;
+  cell_coords(g, xi, yi, zi, cx, cy, cz);
+  const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < g.nc[0] - 1 ? cx + 1 : g.nc[0] - 1;
+  int n = 0;
+  int* out = FILL ? jlist + nbr_off[i] : nullptr;
+  for (int dz = -1; dz <= 1; dz++) {
+    const int z = cz + dz;
+    if (z < 0 || z >= g.nc[2]) continue;
+    for (int dy = -1; dy <= 1; dy++) {
+      const int y = cy + dy;
+      if (y < 0 || y >= g.nc[1]) continue;
+      const int rowc = (z * g.nc[1] + y) * g.nc[0];
+      const int beg = cell_start[rowc + x0], end = cell_start[rowc + x1 + 1];
+      for (int q = beg; q < end; q++) {
+        const double ddx = xs[3 * q] - xi, ddy = xs[3 * q + 1] - yi, ddz = xs[3 * q + 2] - zi;
+        const double r2 = ddx * ddx + ddy * ddy + ddz * ddz;
+        if (r2 <= cut2 && q != p) {  // rsq <= cutneighsq, as LAMMPS' npair full/bin
+          if (FILL) out[n] = order[q];
+          n++;
+        }
+      }
+    }
+  }
+  if (!FILL) numneigh[i] = n;
+}
+
+__global__ void iota_kernel(int* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+
+}  // namespace
+
+void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrScratch& s, hipStream_t st) {
+  (void)hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(g.ncell + 1), st);
+  (void)hipMemsetAsync(s.cursor, 0, sizeof(int) * (size_t)g.ncell, st);
+  if (ntotal <= 0) {
+    (void)hipMemsetAsync(s.cell_start, 0, sizeof(int) * (size_t)(g.ncell + 1), st);
+    return;
+  }
+  const dim3 grid((ntotal + 255) / 256), block(256);
+  hipLaunchKernelGGL(nbr_bin_count_kernel, grid, block, 0, st, d_x, ntotal, g, s.cell_id, s.cell_count);
+  hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, s.cell_count, s.cell_start, g.ncell);
+  hipLaunchKernelGGL(nbr_bin_fill_kernel, grid, block, 0, st, s.cell_id, s.cell_start, s.cursor, s.order, ntotal);
+  hipLaunchKernelGGL(nbr_bin_sort_kernel, dim3((g.ncell + 255) / 256), block, 0, st, s.cell_start, s.order, g.ncell);
+  hipLaunchKernelGGL(nbr_gather_kernel, grid, block, 0, st, d_x, s.order, ntotal, s.xs);
+}
+
+void launch_nbr_count(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int* d_numneigh,
+                      int* d_nbr_off, hipStream_t st) {
+  if (nlocal > 0 && ntotal > 0)
+    hipLaunchKernelGGL(nbr_search_kernel<false>, dim3((ntotal + 255) / 256), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
+                       nlocal, ntotal, cutneigh * cutneigh, d_numneigh, nullptr, nullptr);
+  hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, d_numneigh, d_nbr_off, nlocal);
+}
+
+void launch_nbr_fill(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, const int* d_nbr_off,
+                     int* d_jlist, int* d_ilist, hipStream_t st) {
+  if (nlocal <= 0 || ntotal <= 0) return;
+  hipLaunchKernelGGL(nbr_search_kernel<true>, dim3((ntotal + 255) / 256), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
+                     nlocal, ntotal, cutneigh * cutneigh, nullptr, d_nbr_off, d_jlist);
+  hipLaunchKernelGGL(iota_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, st, d_ilist, nlocal);
+}
+
+}  // namespace ani

@@ -193,7 +193,7 @@ ANI1X_SAE = [-0.600953, -38.08316, -54.707756, -75.194466]
 ANI1X_HIDDEN = {"H": [160, 128, 96], "C": [144, 112, 96], "N": [128, 112, 96], "O": [128, 112, 96]}
 
 
-def _fill_weights(model: AniModel, num_models: int, seed: int, bias_scale: float) -> None:
+def _fill_weights(model: AniModel, num_models: int, seed: int, bias_scale: float, out_scale: float = 0.2) -> None:
     model.weights = []
     stream = 0
     for mi in range(num_models):
@@ -207,7 +207,7 @@ def _fill_weights(model: AniModel, num_models: int, seed: int, bias_scale: float
                     # output layer at 1/5 of that: atomic energies ~0.1 Ha and water forces of rms ~15 kcal/mol/A,
                     # the scale of a trained ANI-2x (unit-variance outputs give rms ~80, which would make the
                     # absolute force tolerances of the tests 5x harder than they are for the real model)
-                    a *= 0.2
+                    a *= out_scale
                 stream += 1
                 W = (_uniform_pm1(o * i, seed * 1000003 + stream) * a).astype(np.float32).reshape(o, i)
                 stream += 1
@@ -218,11 +218,13 @@ def _fill_weights(model: AniModel, num_models: int, seed: int, bias_scale: float
 
 
 def synthetic_model(kind: str = "ani2x", num_models: int = 8, seed: int = 2024,
-                    bias_scale: float = 0.05) -> AniModel:
+                    bias_scale: float = 0.05, out_scale: float = 0.2) -> AniModel:
     """Shape-identical stand-in for a trained model.
 
     ``kind``: ``"ani2x"`` (7 species, AEV 1008, nets of SURVEY.md §8a row a7), ``"ani1x"`` (4 species,
-    AEV 384) or ``"tiny"`` (3 species, AEV 51, small nets — unit-test size).
+    AEV 384) or ``"tiny"`` (3 species, AEV 51, small nets — unit-test size).  ``out_scale`` scales the output
+    layer (0.2: force magnitudes of a trained ANI-2x on water; the MD stand-in uses 0.02 so that the random energy
+    surface, which has no minimum at the starting structure, stays within a few kT).
     """
     if kind == "ani2x":
         sp, sae, hid = ANI2X_SPECIES, ANI2X_SAE, ANI2X_HIDDEN
@@ -244,5 +246,5 @@ def synthetic_model(kind: str = "ani2x", num_models: int = 8, seed: int = 2024,
     else:
         raise ValueError(kind)
     m.dims = [[m.aev_len] + hid[s] + [1] for s in sp]
-    _fill_weights(m, num_models, seed, bias_scale)
+    _fill_weights(m, num_models, seed, bias_scale, out_scale)
     return m
