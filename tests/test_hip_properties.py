@@ -1,0 +1,123 @@
+"""GPU tests beyond the fixtures: size-independent properties at the benchmark's full size, rank-count invariance of
+the HIP path, the fp32-vs-fp64 force sweep on mixed-species boxes (BASELINE.json configs[4]: reactive C/H/N/O box,
+"fp32 vs fp64 force tolerance sweep"), and the error paths of the C ABI."""
+import numpy as np
+import pytest
+
+from lammps_ani_amd import harness as hx
+
+pytestmark = pytest.mark.gpu
+
+F_TOL = 2.3e-3  # kcal/mol/A = 1e-4 eV/A (north-star bar)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from lammps_ani_amd import ani_hip
+    return ani_hip
+
+
+def _folded(inp, force):
+    f = force[: inp.nlocal].copy()
+    np.add.at(f, inp.owner_lidx, force[inp.nlocal:])
+    return f
+
+
+def test_full_size_water_box_properties(model_cache, hip):
+    """The 100 002-atom benchmark box (too big for the oracle inside a unit test): properties that hold at any size.
+      * Newton's third law: forces folded onto owners sum to zero (fp32 noise of 1e5 atoms);
+      * translation invariance: shifting every atom by the same vector leaves energy and forces unchanged;
+      * the virial equals sum_i r_i (x) f_i over local+ghost atoms (the reference's identity for a potential that
+        depends on differences only), which ties the separately accumulated virial to the forces."""
+    p = model_cache("ani2x", 1, 2024)
+    sysm = hx.spatial_sort(hx.water_box(100002))
+    inp = hx.decompose(sysm)
+    ani = hip.ANI(p, 0)
+    a = ani.compute(inp, ago=0)
+    fa = _folded(inp, a["force"])
+    assert np.isfinite(a["energy"])
+    assert np.abs(fa.sum(0)).max() < 0.5                       # |sum F| over 1e5 atoms with rms force ~16
+    assert 5.0 < np.sqrt((fa ** 2).mean()) < 50.0
+    shifted = hx.RankInput(**{**inp.__dict__, "x": inp.x + np.array([0.37, -1.21, 2.5])})
+    b = ani.compute(shifted, ago=1)
+    assert abs(b["energy"] - a["energy"]) < 0.05               # 4.8e7 kcal/mol total, fp32 per-atom terms
+    assert np.abs(b["force"] - a["force"]).max() < F_TOL
+    w = (inp.x[:, :, None] * a["force"][:, None, :]).sum(0)    # sum r (x) f, all atoms incl. ghosts
+    w = 0.5 * (w + w.T)
+    assert np.abs(w - a["virial"]).max() < 2e-3 * np.abs(a["virial"]).max() + 1.0
+    ani.close()
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 2)], ids=["2ranks", "8ranks"])
+def test_rank_count_invariance_on_device(grid, model_cache, hip):
+    """LAMMPS' brick decomposition: the per-rank energies sum to the single-rank energy and the folded forces agree."""
+    p = model_cache("ani2x", 2, 2024)
+    sysm = hx.random_box(1800, 7, 30.0, seed=12)
+    one = hx.decompose(sysm)
+    ani = hip.ANI(p, 0)
+    r1 = ani.compute(one, ago=0)
+    f1 = np.zeros((sysm.natoms, 3))
+    f1[one.tag[: one.nlocal]] = _folded(one, r1["force"])
+    e, F = 0.0, np.zeros((sysm.natoms, 3))
+    vir = np.zeros((3, 3))
+    for rank in range(int(np.prod(grid))):
+        inp = hx.decompose(sysm, grid, rank)
+        r = ani.compute(inp, ago=0)
+        e += r["energy"]
+        vir += r["virial"]
+        np.add.at(F, inp.tag, r["force"])      # ghost rows land on their owners' global index
+    assert abs(e - r1["energy"]) < 2e-2
+    assert np.abs(F - f1).max() < F_TOL
+    assert np.abs(vir - r1["virial"]).max() < 0.2
+    ani.close()
+
+
+@pytest.mark.parametrize("natoms,L", [(600, 22.0), (1200, 24.0), (2400, 27.0), (4000, 30.0)])
+def test_fp32_vs_fp64_force_sweep_mixed_species(natoms, L, model_cache, hip):
+    """C/H/N/O boxes of growing density (0.056 .. 0.148 atoms/A^3, up to ~75 radial neighbours per atom): the fp32
+    MFMA path against the fp64 kernels of the same library."""
+    p = model_cache("ani1x", 4, 77)
+    inp = hx.decompose(hx.random_box(natoms, 4, L, seed=natoms))
+    a32 = hip.ANI(p, 0, use_single=True)
+    a64 = hip.ANI(p, 0, use_single=False)
+    r32, r64 = a32.compute(inp, ago=0), a64.compute(inp, ago=0)
+    df = np.abs(r32["force"] - r64["force"])
+    print(f"natoms {natoms}: max|dF| {df.max():.2e} rms {np.sqrt((df ** 2).mean()):.2e} max|F| {np.abs(r64['force']).max():.1f}")
+    assert df.max() < F_TOL
+    assert abs(r32["energy"] - r64["energy"]) < 2e-3 * max(1.0, natoms / 100.0)
+    assert np.abs(r32["eatom"] - r64["eatom"]).max() < 2e-3
+    a32.close()
+    a64.close()
+
+
+def test_neighbour_capacity_is_reported_not_ignored(model_cache, hip):
+    """More than 96 neighbours inside the 3.5 A angular cutoff (a density no real system has): the step must fail with
+    ANI_ERR_CAPACITY, never return numbers computed from a truncated neighbourhood."""
+    p = model_cache("ani2x", 1, 2024)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1.6, 1.6, size=(130, 3))              # 130 atoms in a 3.2 A cube
+    s = hx.System(x, np.full(130, 1, np.int32), np.full(3, -30.0), np.full(3, 30.0), (False,) * 3)
+    inp = hx.decompose(s)
+    ani = hip.ANI(p, 0)
+    with pytest.raises(hip.AniError, match="capacity"):
+        ani.compute(inp, ago=0)
+    # the handle stays usable
+    ok = hx.decompose(hx.water_box(300, seed=2))
+    assert np.isfinite(ani.compute(ok, ago=0)["energy"])
+    ani.close()
+
+
+def test_argument_errors(model_cache, hip):
+    p = model_cache("tiny", 2, 5)   # 3 species
+    ani = hip.ANI(p, 0)
+    inp = hx.decompose(hx.random_box(60, 3, 14.0, seed=1))
+    with pytest.raises(hip.AniError, match="ago != 0"):
+        ani.compute(inp, ago=1)                              # no list cached yet
+    bad = hx.RankInput(**{**inp.__dict__, "types": np.where(np.arange(inp.ntotal) == 5, 9, inp.types).astype(np.int32)})
+    with pytest.raises(hip.AniError, match="species"):
+        ani.compute(bad, ago=0)
+    good = ani.compute(inp, ago=0)
+    assert np.isfinite(good["energy"])
+    with pytest.raises(hip.AniError):
+        hip.ANI(p, 0, use_num_models=5)                      # the file holds 2 members
+    ani.close()
