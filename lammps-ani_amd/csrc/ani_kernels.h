@@ -40,7 +40,9 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
 
 // x (double [ntotal*3]) + species -> float4 {x,y,z,bits of cmap[species]}
 struct SpeciesMap { int m[kMaxSpecies]; };
-void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, hipStream_t st);
+// also clears this step's accumulators: fbuf[3*ntotal] and virial_acc[9] (no separate memsets)
+void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
+                 double* virial_acc, hipStream_t st);
 
 // rebuild-time preparation: neighbour offsets, species buckets.  All outputs device arrays.
 struct PrepOut {

@@ -342,6 +342,100 @@ __device__ __forceinline__ void stream_pair(const FastLds& L, int nbk, int t, in
   ib = e0.w + b;
 }
 
+// v[lane ^ OFF] for OFF = 1, 2, 4, 8 as DPP moves (VALU, no LDS crossbar round trip), 16 as a swizzle, 32 as a permute
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int x = __float_as_int(v);
+  int y;
+  if constexpr (OFF == 1) {
+    y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  } else if constexpr (OFF == 2) {
+    y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  } else if constexpr (OFF == 4) {
+    y = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);  // row_shl:4 into banks 0,2
+    y = __builtin_amdgcn_update_dpp(y, x, 0x114, 0xf, 0xa, false);  // row_shr:4 into banks 1,3
+  } else if constexpr (OFF == 8) {
+    y = __builtin_amdgcn_mov_dpp(x, 0x128, 0xf, 0xf, true);  // row_ror:8
+  } else if constexpr (OFF == 16) {
+    y = __builtin_amdgcn_ds_swizzle(x, 0x401F);              // bit mode: xor 0x10 within 32 lanes
+  } else {
+    y = __shfl_xor(x, 32);
+  }
+  return __int_as_float(y);
+}
+// one butterfly level of the tile reductions: lanes that differ in bit OFF hold the same row (OFF < TB: sum the
+// row values) or the same column (OFF >= TB: sum the column values); TB is wave-uniform
+template <int OFF, int N>
+__device__ __forceinline__ void tile_level(int TB, float (&rowv)[N], float (&colv)[N]) {
+  if (OFF < TB) {
+#pragma unroll
+    for (int k = 0; k < N; k++) rowv[k] += lane_xor<OFF>(rowv[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; k++) colv[k] += lane_xor<OFF>(colv[k]);
+  }
+}
+template <int N>
+__device__ __forceinline__ void tile_reduce(int TB, float (&rowv)[N], float (&colv)[N]) {
+  tile_level<1, N>(TB, rowv, colv);
+  tile_level<2, N>(TB, rowv, colv);
+  tile_level<4, N>(TB, rowv, colv);
+  tile_level<8, N>(TB, rowv, colv);
+  tile_level<16, N>(TB, rowv, colv);
+  tile_level<32, N>(TB, rowv, colv);
+}
+
+// Backward enumeration: every non-empty species-pair bucket is cut into TILES of 64 lanes laid out as
+// TA rows x TB columns (TB = 2^k >= the column count, capped at 64; TA = 64 / TB).
+//   s1 != s2 : row = neighbour of species s1, column = neighbour of species s2 (n1 x n2 rectangle);
+//   s1 == s2 : the strict upper triangle of n x n folded into nn/2 rows x nn columns (nn = n rounded up to even):
+//              lane (r, c) holds the pair (r, c) if c > r and the pair (nn-1-r, nn-1-c) if c < r.
+// With that layout the per-neighbour sums of the pair gradients are sums along rows / along columns, i.e. a few
+// xor-shuffles and one plain LDS add per neighbour, instead of six LDS float atomics per pair with ~10-way address
+// conflicts (which cost more than all the arithmetic of the pass).
+// entry: {tile0, a1, n1, a2, n2, outoff, tri | log2(TB) << 1, column blocks}.  Returns the number of tiles.
+template <int NA, int NZ>
+__device__ __forceinline__ int build_tile_table(const AevParams& p, int lane, FastLds& L, int& nbk) {
+  const int nb_all = p.S * (p.S + 1) / 2;
+  int s1 = 0, s2 = 0, n1 = 0, n2 = 0, ntile = 0, tbl = 0, ncb = 1, tri = 0;
+  if (lane < nb_all) {
+    int rem = lane;
+    while (rem >= p.S - s1) { rem -= p.S - s1; s1++; }
+    s2 = s1 + rem;
+    n1 = L.astart[s1 + 1] - L.astart[s1];
+    n2 = L.astart[s2 + 1] - L.astart[s2];
+    int nrows = 0, ncols = 0;
+    if (s1 == s2) {
+      tri = 1;
+      const int nn = (n1 + 1) & ~1;
+      if (n1 >= 2) { nrows = nn >> 1; ncols = nn; }
+    } else if (n1 > 0 && n2 > 0) {
+      nrows = n1; ncols = n2;
+    }
+    if (nrows > 0) {
+      const int cw = min(ncols, 64);
+      tbl = 32 - __clz(cw - 1);  // log2 of the next power of two (cw = 1 -> 0)
+      ncb = (ncols + 63) >> 6;
+      const int TA = 64 >> tbl;
+      ntile = ((nrows + TA - 1) / TA) * ncb;
+    }
+  }
+  int incl = ntile;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  const unsigned long long m = __ballot(ntile > 0);
+  if (ntile > 0) {
+    int* e = L.tb + 8 * lanes_below(m);
+    e[0] = incl - ntile; e[1] = L.astart[s1]; e[2] = n1; e[3] = L.astart[s2]; e[4] = n2;
+    e[5] = p.radial_len + lane * (NA * NZ); e[6] = tri | (tbl << 1); e[7] = ncb;
+  }
+  nbk = __popcll(m);
+  return __shfl(incl, 63);
+}
+
 template <int NA, int NZ>
 __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row, const Prefetched& pf,
                                                int lane) {
@@ -531,20 +625,45 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     }
   }
   int nbk;
-  const int total = build_bucket_table<NA, NZ>(p, lane, L, nbk);
+  const int ntiles = build_tile_table<NA, NZ>(p, lane, L, nbk);
   wave_sync();
 
-  // ---- angular: lane = pair of the padded stream ----
+  // ---- angular: lane = pair of a TA x TB tile (see build_tile_table) ----
   const float cA = -p.EtaA * kLog2e;
   const float revA = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
 #ifdef ABL_NO_ANG
-  for (int base = 0; base < 0; base += 64) {
+  for (int tile = 0; tile < 0; tile++) {
 #else
-  for (int base = 0; base < total; base += 64) {
+  for (int tile = 0; tile < ntiles; tile++) {
 #endif
-    int ia, ib, outoff;
+    int e = 0;
+    for (int k = 1; k < nbk; k++)
+      if (tile >= L.tb[8 * k]) e = k;
+    const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);
+    const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);
+    const int a1 = e0.y, n1 = e0.z, a2 = e0.w, n2 = e1.x, outoff = e1.y, ncb = e1.w;
+    const bool tri = e1.z & 1;
+    const int tbl = e1.z >> 1, TB = 1 << tbl;
+    const int u = tile - e0.x;
+    const int rb = ncb > 1 ? u / ncb : u;
+    const int cb = u - rb * ncb;
+    const int col = (cb << 6) + (lane & (TB - 1));
+    const int r = rb * (64 >> tbl) + (lane >> tbl);
+    const int nn = (n1 + 1) & ~1;
+    const bool above = col > r;  // tri only: which of the two folded pairs this lane holds
     bool valid;
-    stream_pair(L, nbk, base + lane, ia, ib, outoff, valid);
+    int ia, ib;
+    if (tri) {
+      const int a = above ? r : nn - 1 - r;
+      const int b = above ? col : nn - 1 - col;
+      valid = col != r && r < (nn >> 1) && col < nn && b < n1;
+      ia = a1 + (valid ? a : 0);
+      ib = a1 + (valid ? b : 1);   // distinct neighbours keep the masked geometry finite
+    } else {
+      valid = r < n1 && col < n2;
+      ia = a1 + (valid ? r : 0);
+      ib = a2 + (valid ? col : 0);
+    }
     const float4 A = L.ad[ia], B = L.ad[ib];
     const float inv_ra = frcp(A.w), inv_rb = frcp(B.w);
     const float inv_rr = inv_ra * inv_rb;
@@ -552,7 +671,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     const float c = 0.95f * cosv;
     const float s2 = fmaxf(1.f - c * c, 1e-12f);
     const float inv_s = frsq(s2);
-    const float s = s2 * inv_s;
+    const float sn = s2 * inv_s;
     const float fa = L.afc[ia], fb = L.afc[ib];
     const float dfa = -0.5f * p.pi_over_Rca * fsin_rev(A.w * revA);
     const float dfb = -0.5f * p.pi_over_Rca * fsin_rev(B.w * revA);
@@ -560,12 +679,12 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     float f1[NZ], df1[NZ];
 #pragma unroll
     for (int z = 0; z < NZ; z++) {
-      const float bz = fmaxf(0.5f * (1.f + c * p.cosZ[z] + s * p.sinZ[z]), 0.f);
+      const float bz = fmaxf(0.5f * (1.f + c * p.cosZ[z] + sn * p.sinZ[z]), 0.f);
       const float pm1 = fexp2((p.Zeta - 1.f) * flog2(bz));
       f1[z] = pm1 * bz;
-      df1[z] = p.Zeta * pm1 * 0.5f * (s * p.cosZ[z] - c * p.sinZ[z]) * inv_s;
+      df1[z] = p.Zeta * pm1 * 0.5f * (sn * p.cosZ[z] - c * p.sinZ[z]) * inv_s;
     }
-    const float* gg = L.row + outoff;
+    const float4* gg4 = reinterpret_cast<const float4*>(L.row + outoff);  // outoff is a multiple of NA*NZ
     float Aq = 0.f, Bq = 0.f, Cq = 0.f;
 #pragma unroll
     for (int sa = 0; sa < NA; sa++) {
@@ -574,36 +693,71 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       const float df2 = -2.f * p.EtaA * dr * f2;
       float g1 = 0.f, gd1 = 0.f;
 #pragma unroll
-      for (int z = 0; z < NZ; z++) {
-        const float gv = gg[sa * NZ + z];
-        g1 = fmaf(gv, f1[z], g1);
-        gd1 = fmaf(gv, df1[z], gd1);
+      for (int z4 = 0; z4 < NZ / 4; z4++) {
+        const float4 gv = gg4[sa * (NZ / 4) + z4];
+        g1 = fmaf(gv.x, f1[4 * z4], g1); gd1 = fmaf(gv.x, df1[4 * z4], gd1);
+        g1 = fmaf(gv.y, f1[4 * z4 + 1], g1); gd1 = fmaf(gv.y, df1[4 * z4 + 1], gd1);
+        g1 = fmaf(gv.z, f1[4 * z4 + 2], g1); gd1 = fmaf(gv.z, df1[4 * z4 + 2], gd1);
+        g1 = fmaf(gv.w, f1[4 * z4 + 3], g1); gd1 = fmaf(gv.w, df1[4 * z4 + 3], gd1);
       }
       Aq = fmaf(f2, gd1, Aq);
       Cq = fmaf(f2, g1, Cq);
       Bq = fmaf(df2, g1, Bq);
     }
-#ifdef ABL_NO_LATOM
-    asm volatile("" ::"v"(Aq), "v"(Bq), "v"(Cq));
-    if (false) {
-#else
-    if (valid) {
-#endif
-      const float P = fa * fb;
-      Aq *= 2.f * P * 0.95f;
-      Bq *= P;       // 2 * P * 0.5
-      Cq *= 2.f;
-      const float ca = Aq * inv_rr;
-      const float ta = (Bq + Cq * dfa * fb) * inv_ra - Aq * cosv * inv_ra * inv_ra;
-      const float tb = (Bq + Cq * fa * dfb) * inv_rb - Aq * cosv * inv_rb * inv_rb;
-      const int qa = L.aidx[ia], qb = L.aidx[ib];
-      atomicAdd(&L.gd[3 * qa + 0], ca * B.x + ta * A.x);
-      atomicAdd(&L.gd[3 * qa + 1], ca * B.y + ta * A.y);
-      atomicAdd(&L.gd[3 * qa + 2], ca * B.z + ta * A.z);
-      atomicAdd(&L.gd[3 * qb + 0], ca * A.x + tb * B.x);
-      atomicAdd(&L.gd[3 * qb + 1], ca * A.y + tb * B.y);
-      atomicAdd(&L.gd[3 * qb + 2], ca * A.z + tb * B.z);
+    // gradient of this pair w.r.t. the two neighbour displacements; zero for masked lanes
+    const float P = valid ? fa * fb : 0.f;
+    Aq *= 2.f * P * 0.95f;
+    Bq *= P;       // 2 * P * 0.5
+    Cq *= valid ? 2.f : 0.f;
+    const float ca = Aq * inv_rr;
+    const float ta = (Bq + Cq * dfa * fb) * inv_ra - Aq * cosv * inv_ra * inv_ra;
+    const float tb = (Bq + Cq * fa * dfb) * inv_rb - Aq * cosv * inv_rb * inv_rb;
+    float va[3] = {ca * B.x + ta * A.x, ca * B.y + ta * A.y, ca * B.z + ta * A.z};  // d/d(neighbour ia)
+    float vb[3] = {ca * A.x + tb * B.x, ca * A.y + tb * B.y, ca * A.z + tb * B.z};  // d/d(neighbour ib)
+#ifndef ABL_NO_LATOM
+    const bool row_writer = (lane & (TB - 1)) == 0, col_writer = (lane >> tbl) == 0;
+    if (!tri) {
+      // rows share ia, columns share ib
+      tile_reduce<3>(TB, va, vb);
+      if (row_writer && r < n1) {
+        const int q = L.aidx[a1 + r];
+        L.gd[3 * q] += va[0]; L.gd[3 * q + 1] += va[1]; L.gd[3 * q + 2] += va[2];
+      }
+      if (col_writer && col < n2) {
+        const int q = L.aidx[a2 + col];
+        L.gd[3 * q] += vb[0]; L.gd[3 * q + 1] += vb[1]; L.gd[3 * q + 2] += vb[2];
+      }
+    } else {
+      // lanes above the diagonal: ia = r, ib = col; lanes below: ia = nn-1-r, ib = nn-1-col
+      float rw[6], cw[6];   // [0..2] above-diagonal part, [3..5] below
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        rw[k] = above ? va[k] : 0.f; rw[3 + k] = above ? 0.f : va[k];
+        cw[k] = above ? vb[k] : 0.f; cw[3 + k] = above ? 0.f : vb[k];
+      }
+      tile_reduce<6>(TB, rw, cw);
+      const bool rok = row_writer && r < (nn >> 1);
+      if (rok && r < n1) {
+        const int q = L.aidx[a1 + r];
+        L.gd[3 * q] += rw[0]; L.gd[3 * q + 1] += rw[1]; L.gd[3 * q + 2] += rw[2];
+      }
+      if (rok && nn - 1 - r < n1) {
+        const int q = L.aidx[a1 + nn - 1 - r];
+        L.gd[3 * q] += rw[3]; L.gd[3 * q + 1] += rw[4]; L.gd[3 * q + 2] += rw[5];
+      }
+      const bool cok = col_writer && col < nn;
+      if (cok && col < n1) {
+        const int q = L.aidx[a1 + col];
+        L.gd[3 * q] += cw[0]; L.gd[3 * q + 1] += cw[1]; L.gd[3 * q + 2] += cw[2];
+      }
+      if (cok && nn - 1 - col < n1) {
+        const int q = L.aidx[a1 + nn - 1 - col];
+        L.gd[3 * q] += cw[3]; L.gd[3 * q + 1] += cw[4]; L.gd[3 * q + 2] += cw[5];
+      }
     }
+#else
+    asm volatile("" ::"v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(vb[0]), "v"(vb[1]), "v"(vb[2]));
+#endif
   }
   wave_sync();
 
@@ -653,7 +807,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
 }
 
 template <int NA, int NZ>
-__global__ __launch_bounds__(64 * kWavesB) void aev_backward_fast(AevParams p, AevArgs a, int cap, int rowf) {
+__global__ __launch_bounds__(64 * kWavesB, 3) void aev_backward_fast(AevParams p, AevArgs a, int cap, int rowf) {
   extern __shared__ float4 smem4[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, true, rowf), cap, true, rowf);
@@ -949,11 +1103,11 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, false, rowf) * 4 * kWaves;
     if (fast_kind(p) == 1) {
-      static bool once = (hipFuncSetAttribute((const void*)aev_forward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      static bool once = ((void)hipFuncSetAttribute((const void*)aev_forward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
       hipLaunchKernelGGL((aev_forward_fast<8, 4>), dim3(persistent_blocks(aev_forward_fast<8, 4>, a.nrows, kWaves, lds)), block, lds, st, p, a, cap, rowf);
     } else {
-      static bool once = (hipFuncSetAttribute((const void*)aev_forward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      static bool once = ((void)hipFuncSetAttribute((const void*)aev_forward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
       hipLaunchKernelGGL((aev_forward_fast<4, 8>), dim3(persistent_blocks(aev_forward_fast<4, 8>, a.nrows, kWaves, lds)), block, lds, st, p, a, cap, rowf);
     }
@@ -972,11 +1126,11 @@ void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, true, rowf) * 4 * kWavesB;
     if (fast_kind(p) == 1) {
-      static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      static bool once = ((void)hipFuncSetAttribute((const void*)aev_backward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
       hipLaunchKernelGGL((aev_backward_fast<8, 4>), dim3(persistent_blocks(aev_backward_fast<8, 4>, a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap, rowf);
     } else {
-      static bool once = (hipFuncSetAttribute((const void*)aev_backward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+      static bool once = ((void)hipFuncSetAttribute((const void*)aev_backward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
       (void)once;
       hipLaunchKernelGGL((aev_backward_fast<4, 8>), dim3(persistent_blocks(aev_backward_fast<4, 8>, a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap, rowf);
     }

@@ -7,19 +7,22 @@
 namespace ani {
 
 __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int ntotal, SpeciesMap cmap,
-                            float4* __restrict__ out) {
+                            float4* __restrict__ out, float* __restrict__ fbuf, double* __restrict__ virial_acc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 9) virial_acc[i] = 0.0;
   if (i >= ntotal) return;
   // coordinates.to(dtype): src/ani_csrc/ani.cpp:206-207.  The species stored next to the position is the index the
   // AEV kernels use (compact index among the species present in this system, see ani_hip.cpp:specialize).
   const int sp = species[i];
   const int cs = (sp >= 0 && sp < kMaxSpecies) ? cmap.m[sp] : 0;
   out[i] = make_float4((float)x[3 * i], (float)x[3 * i + 1], (float)x[3 * i + 2], __int_as_float(cs));
+  fbuf[3 * i] = 0.f; fbuf[3 * i + 1] = 0.f; fbuf[3 * i + 2] = 0.f;
 }
 
-void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, hipStream_t st) {
-  if (ntotal <= 0) return;
-  hipLaunchKernelGGL(pack_kernel, dim3((ntotal + 255) / 256), dim3(256), 0, st, d_x, d_species, ntotal, cmap, xyzs);
+void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
+                 double* virial_acc, hipStream_t st) {
+  hipLaunchKernelGGL(pack_kernel, dim3(ntotal > 0 ? (ntotal + 255) / 256 : 1), dim3(256), 0, st, d_x, d_species, ntotal, cmap,
+                     xyzs, fbuf, virial_acc);
 }
 
 // ---- rebuild-time preparation ------------------------------------------------------------------------
