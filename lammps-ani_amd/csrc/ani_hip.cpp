@@ -525,7 +525,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   if (!h->use_single) return run_step64(h, d_x, eflag_atom, vflag, d_f, f_accumulate, d_ev, d_eatom, st);
   const HostModel& m = h->model;
   HIP_TRY(h, h->xyzs.reserve(h->ntotal));
-  HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 3));
+  HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 4));  // one float4 per atom
   HIP_TRY(h, h->partial.reserve(256));
   HIP_TRY(h, h->virial_acc.reserve(9));
   HIP_TRY(h, h->err_flag.reserve(1, true));

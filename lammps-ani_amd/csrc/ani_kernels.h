@@ -40,7 +40,7 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
 
 // x (double [ntotal*3]) + species -> float4 {x,y,z,bits of cmap[species]}
 struct SpeciesMap { int m[kMaxSpecies]; };
-// also clears this step's accumulators: fbuf[3*ntotal] and virial_acc[9] (no separate memsets)
+// also clears this step's accumulators: fbuf[4*ntotal] and virial_acc[9] (no separate memsets)
 void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
                  double* virial_acc, hipStream_t st);
 
@@ -66,7 +66,7 @@ struct AevArgs {
   int nrows;
   float* aev;        // [nrows][aev_stride]
   const float* gaev; // backward only
-  float* fbuf;       // backward: [ntotal*3] float accumulators (Hartree/Angstrom), atomically added
+  float* fbuf;       // backward: [ntotal*4] float accumulators {fx,fy,fz,-} (Hartree/Angstrom), atomically added
   double* virial;    // backward: [9] (Hartree), atomically added; may be NULL
   int* err_flag;     // set to 1 on LDS capacity overflow
 };
@@ -107,7 +107,7 @@ struct FinishArgs {
   const int* ilist;
   const int* species;    // [ntotal]
   double sae[kMaxSpecies];
-  const float* fbuf;     // [ntotal*3]
+  const float* fbuf;     // [ntotal*4] {fx,fy,fz,-}
   int ntotal;
   const double* virial_acc;  // [9] Hartree (unsymmetrised), or NULL
   double* f_out;         // [ntotal*3] kcal/mol/A

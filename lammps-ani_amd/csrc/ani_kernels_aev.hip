@@ -179,31 +179,36 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
 // The list is walked in super-chunks of 4 x 64 candidates: all jlist loads of a super-chunk are issued first, then
 // all position gathers, so a typical ~150-neighbour centre costs two dependent memory round trips, not six.
 // The first super-chunk arrives preloaded (Prefetched: issued one centre ahead by the persistent loop of the kernel).
+// NCH: 64-lane chunks of the list held in registers per centre (3 when no centre has more than 192 list entries,
+// e.g. water at 7.1 A: ~150; else 4) -- every chunk is 5 VGPRs in each of the two prefetch stages.
+template <int NCH>
 struct Prefetched {
   int4 info;
   float4 xi;
-  int jj[4];
-  float4 xx[4];
+  int jj[NCH];
+  float4 xx[NCH];
 };
 __device__ __forceinline__ int4 load_info(const AevArgs& a, int row) {
   return row < a.nrows ? a.row_info[row] : make_int4(-1, 0, 0, -1);
 }
-__device__ __forceinline__ void load_j(const AevArgs& a, const int4 info, int lane, int (&jj)[4]) {
+template <int NCH>
+__device__ __forceinline__ void load_j(const AevArgs& a, const int4 info, int lane, int (&jj)[NCH]) {
   const int i = info.x < 0 ? 0 : info.x;
 #pragma unroll
-  for (int c = 0; c < 4; c++) {
+  for (int c = 0; c < NCH; c++) {
     const int q = 64 * c + lane;
     jj[c] = q < info.z ? a.jlist[info.y + q] : i;
   }
 }
-__device__ __forceinline__ void gather_x(const AevArgs& a, const int4 info, const int (&jj)[4], float4& xi, float4 (&xx)[4]) {
+template <int NCH>
+__device__ __forceinline__ void gather_x(const AevArgs& a, const int4 info, const int (&jj)[NCH], float4& xi, float4 (&xx)[NCH]) {
   xi = a.xyzs[info.x < 0 ? 0 : info.x];
 #pragma unroll
-  for (int c = 0; c < 4; c++) xx[c] = a.xyzs[jj[c]];
+  for (int c = 0; c < NCH; c++) xx[c] = a.xyzs[jj[c]];
 }
 
-template <bool BWD>
-__device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs& a, const Prefetched& pf, int lane, int cap, FastLds& L,
+template <bool BWD, int NCH>
+__device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs& a, const Prefetched<NCH>& pf, int lane, int cap, FastLds& L,
                                                int& nrad, int& nang, bool& over) {
   const int4 info = pf.info;
   const int i = info.x;
@@ -216,23 +221,23 @@ __device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs
   int cr = 0, ca = 0;  // lane s: count of species s
   const float half_inv_Rcr = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;  // r/(2 Rcr) revolutions
   const float half_inv_Rca = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
-  for (int base0 = 0; base0 < n; base0 += 256) {
-    int jj[4];
-    float4 xx[4];
+  for (int base0 = 0; base0 < n; base0 += 64 * NCH) {
+    int jj[NCH];
+    float4 xx[NCH];
     if (base0 == 0) {
 #pragma unroll
-      for (int c = 0; c < 4; c++) { jj[c] = pf.jj[c]; xx[c] = pf.xx[c]; }
-    } else {  // more than 256 list entries: rare, loaded in place
+      for (int c = 0; c < NCH; c++) { jj[c] = pf.jj[c]; xx[c] = pf.xx[c]; }
+    } else {  // more than 64 * NCH list entries: rare, loaded in place
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
+      for (int c = 0; c < NCH; c++) {
         const int q = base0 + 64 * c + lane;
         jj[c] = q < n ? a.jlist[beg + q] : i;
       }
 #pragma unroll
-      for (int c = 0; c < 4; c++) xx[c] = a.xyzs[jj[c]];
+      for (int c = 0; c < NCH; c++) xx[c] = a.xyzs[jj[c]];
     }
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < NCH; c++) {
       const int base = base0 + 64 * c;
       if (base < n) {  // wave-uniform
         const bool valid = base + lane < n;
@@ -436,14 +441,14 @@ __device__ __forceinline__ int build_tile_table(const AevParams& p, int lane, Fa
   return __shfl(incl, 63);
 }
 
-template <int NA, int NZ>
-__device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row, const Prefetched& pf,
-                                               int lane) {
+template <int NA, int NZ, int NCH>
+__device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row,
+                                               const Prefetched<NCH>& pf, int lane) {
   constexpr int NR = 16, Q = 64 / NA;
   for (int e = lane; e < (p.aev_stride >> 2); e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
   int nrad, nang;
   bool over;
-  compact_sorted<false>(p, a, pf, lane, cap, L, nrad, nang, over);
+  compact_sorted<false, NCH>(p, a, pf, lane, cap, L, nrad, nang, over);
   if (over && lane == 0) atomicOr(a.err_flag, 1);
   wave_sync();
 
@@ -550,10 +555,10 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
 // Persistent waves: wave w handles rows w, w + W, w + 2W, ...  The three dependent loads of a centre
 // (row_info -> jlist -> positions) are software-pipelined across centres: while centre c is being processed, the
 // position gathers of c+1, the list loads of c+2 and the row_info of c+3 are in flight.
-#define ANI_PERSISTENT_LOOP(KW, PRE_CALL, CENTRE_CALL)                                                   \
+#define ANI_PERSISTENT_LOOP(KW, NCH, PRE_CALL, CENTRE_CALL)                                                  \
   const int nw = gridDim.x * KW;                                                                          \
   int row = blockIdx.x * KW + wave;                                                                       \
-  Prefetched cur, nxt;                                                                                    \
+  Prefetched<NCH> cur, nxt;                                                                               \
   cur.info = load_info(a, row);                                                                           \
   nxt.info = load_info(a, row + nw);                                                                      \
   int4 info2 = load_info(a, row + 2 * nw);                                                                \
@@ -563,36 +568,36 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
   while (row < a.nrows) {                                                                                 \
     PRE_CALL;                                                                                             \
     gather_x(a, nxt.info, nxt.jj, nxt.xi, nxt.xx);                                                        \
-    int jj2[4];                                                                                           \
+    int jj2[NCH];                                                                                         \
     load_j(a, info2, lane, jj2);                                                                          \
     const int4 info3 = load_info(a, row + 3 * nw);                                                        \
     if (cur.info.x >= 0) { CENTRE_CALL; }                                                                 \
     cur = nxt;                                                                                            \
     nxt.info = info2;                                                                                     \
-    _Pragma("unroll") for (int c = 0; c < 4; c++) nxt.jj[c] = jj2[c];                                     \
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) nxt.jj[c] = jj2[c];                                   \
     info2 = info3;                                                                                        \
     row += nw;                                                                                            \
   }
 
-template <int NA, int NZ>
+template <int NA, int NZ, int NCH>
 __global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, AevArgs a, int cap, int rowf) {
   extern __shared__ float4 smem4[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, false, rowf), cap, false, rowf);
-  ANI_PERSISTENT_LOOP(kWaves, (void)0, (forward_centre<NA, NZ>(p, a, cap, L, row, cur, lane)))
+  ANI_PERSISTENT_LOOP(kWaves, NCH, (void)0, (forward_centre<NA, NZ, NCH>(p, a, cap, L, row, cur, lane)))
 }
 
-template <int NA, int NZ>
-__device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row, const Prefetched& pf,
-                                                const float4 (&grow)[4], int lane) {
+template <int NA, int NZ, int NCH, int GR>
+__device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row,
+                                                const Prefetched<NCH>& pf, const float4 (&grow)[GR], int lane) {
   constexpr int NR = 16;
   const int4 info = pf.info;
 #pragma unroll
-  for (int c = 0; c < 4; c++)
+  for (int c = 0; c < GR; c++)
     if (lane + 64 * c < (p.aev_stride >> 2)) reinterpret_cast<float4*>(L.row)[lane + 64 * c] = grow[c];
   int nrad, nang;
   bool over;
-  compact_sorted<true>(p, a, pf, lane, cap, L, nrad, nang, over);
+  compact_sorted<true, NCH>(p, a, pf, lane, cap, L, nrad, nang, over);
   if (over && lane == 0) atomicOr(a.err_flag, 1);
   wave_sync();
 
@@ -715,17 +720,23 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     float va[3] = {ca * B.x + ta * A.x, ca * B.y + ta * A.y, ca * B.z + ta * A.z};  // d/d(neighbour ia)
     float vb[3] = {ca * A.x + tb * B.x, ca * A.y + tb * B.y, ca * A.z + tb * B.z};  // d/d(neighbour ib)
 #ifndef ABL_NO_LATOM
+    // radial-list slots of the neighbours this lane may have to update (the reads overlap the butterflies below)
+    const int cbase = tri ? a1 : a2, cmax = (tri ? n1 : n2) - 1;
+    const int qr0 = L.aidx[a1 + min(r, n1 - 1)];
+    const int qc0 = L.aidx[cbase + min(col, cmax)];
+    const int qr1 = tri ? L.aidx[a1 + min(max(nn - 1 - r, 0), n1 - 1)] : 0;
+    const int qc1 = tri ? L.aidx[a1 + min(max(nn - 1 - col, 0), n1 - 1)] : 0;
+    // Sums along rows (lanes sharing ia) and along columns (lanes sharing ib), then ONE lane per neighbour adds the
+    // sum to its LDS accumulator.  Those adds are LDS atomics only to make them fire-and-forget (distinct addresses
+    // within an instruction, so no conflict serialisation): a read-add-write would stall on every LDS round trip.
     const bool row_writer = (lane & (TB - 1)) == 0, col_writer = (lane >> tbl) == 0;
     if (!tri) {
-      // rows share ia, columns share ib
       tile_reduce<3>(TB, va, vb);
       if (row_writer && r < n1) {
-        const int q = L.aidx[a1 + r];
-        L.gd[3 * q] += va[0]; L.gd[3 * q + 1] += va[1]; L.gd[3 * q + 2] += va[2];
+        atomicAdd(&L.gd[3 * qr0], va[0]); atomicAdd(&L.gd[3 * qr0 + 1], va[1]); atomicAdd(&L.gd[3 * qr0 + 2], va[2]);
       }
       if (col_writer && col < n2) {
-        const int q = L.aidx[a2 + col];
-        L.gd[3 * q] += vb[0]; L.gd[3 * q + 1] += vb[1]; L.gd[3 * q + 2] += vb[2];
+        atomicAdd(&L.gd[3 * qc0], vb[0]); atomicAdd(&L.gd[3 * qc0 + 1], vb[1]); atomicAdd(&L.gd[3 * qc0 + 2], vb[2]);
       }
     } else {
       // lanes above the diagonal: ia = r, ib = col; lanes below: ia = nn-1-r, ib = nn-1-col
@@ -738,21 +749,17 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       tile_reduce<6>(TB, rw, cw);
       const bool rok = row_writer && r < (nn >> 1);
       if (rok && r < n1) {
-        const int q = L.aidx[a1 + r];
-        L.gd[3 * q] += rw[0]; L.gd[3 * q + 1] += rw[1]; L.gd[3 * q + 2] += rw[2];
+        atomicAdd(&L.gd[3 * qr0], rw[0]); atomicAdd(&L.gd[3 * qr0 + 1], rw[1]); atomicAdd(&L.gd[3 * qr0 + 2], rw[2]);
       }
       if (rok && nn - 1 - r < n1) {
-        const int q = L.aidx[a1 + nn - 1 - r];
-        L.gd[3 * q] += rw[3]; L.gd[3 * q + 1] += rw[4]; L.gd[3 * q + 2] += rw[5];
+        atomicAdd(&L.gd[3 * qr1], rw[3]); atomicAdd(&L.gd[3 * qr1 + 1], rw[4]); atomicAdd(&L.gd[3 * qr1 + 2], rw[5]);
       }
       const bool cok = col_writer && col < nn;
       if (cok && col < n1) {
-        const int q = L.aidx[a1 + col];
-        L.gd[3 * q] += cw[0]; L.gd[3 * q + 1] += cw[1]; L.gd[3 * q + 2] += cw[2];
+        atomicAdd(&L.gd[3 * qc0], cw[0]); atomicAdd(&L.gd[3 * qc0 + 1], cw[1]); atomicAdd(&L.gd[3 * qc0 + 2], cw[2]);
       }
       if (cok && nn - 1 - col < n1) {
-        const int q = L.aidx[a1 + nn - 1 - col];
-        L.gd[3 * q] += cw[3]; L.gd[3 * q + 1] += cw[4]; L.gd[3 * q + 2] += cw[5];
+        atomicAdd(&L.gd[3 * qc1], cw[3]); atomicAdd(&L.gd[3 * qc1 + 1], cw[4]); atomicAdd(&L.gd[3 * qc1 + 2], cw[5]);
       }
     }
 #else
@@ -766,14 +773,6 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int q = lane; q < nrad; q += 64) {
     const float gx = L.gd[3 * q], gy = L.gd[3 * q + 1], gz = L.gd[3 * q + 2];
-    const int j = L.rj[q];
-#ifdef ABL_NO_GATOM
-    asm volatile("" ::"v"(j));
-#else
-    atomicAdd(&a.fbuf[3 * j + 0], -gx);
-    atomicAdd(&a.fbuf[3 * j + 1], -gy);
-    atomicAdd(&a.fbuf[3 * j + 2], -gz);
-#endif
     fx += gx; fy += gy; fz += gz;
     if (a.virial) {
       const float dx = L.rdx[q], dy = L.rdy[q], dz = L.rdz[q];
@@ -789,11 +788,16 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     fz += __shfl_xor(fz, off);
   }
   const int i = info.x;
-  if (lane == 0) {
-    atomicAdd(&a.fbuf[3 * i + 0], fx);
-    atomicAdd(&a.fbuf[3 * i + 1], fy);
-    atomicAdd(&a.fbuf[3 * i + 2], fz);
+#ifndef ABL_NO_GATOM
+  // neighbour forces, lane = (list slot, component): global float atomics execute at the memory side as 64-byte
+  // requests, so the three components of one atom (one float4 of fbuf) go out from adjacent lanes of ONE instruction
+  // and share a request -- as do atoms that are adjacent both in memory and in the (spatially ordered) list
+  for (int base = 0; base < nrad; base += 16) {
+    const int q = base + (lane >> 2), k = lane & 3;
+    if (q < nrad && k < 3) atomicAdd(&a.fbuf[4 * L.rj[q] + k], -L.gd[3 * q + k]);
   }
+#endif
+  if (lane < 3) atomicAdd(&a.fbuf[4 * i + lane], lane == 0 ? fx : (lane == 1 ? fy : fz));
   if (a.virial) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -806,22 +810,23 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   wave_sync();  // the LDS slice is reused by this wave's next centre
 }
 
-template <int NA, int NZ>
+template <int NA, int NZ, int NCH, int GR>
 __global__ __launch_bounds__(64 * kWavesB, 3) void aev_backward_fast(AevParams p, AevArgs a, int cap, int rowf) {
   extern __shared__ float4 smem4[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, true, rowf), cap, true, rowf);
-  // dE/dAEV row of the current centre: 4 x 16 B per lane, issued BEFORE this iteration's prefetch loads so that the
-  // wait for it (vmcnt counts in order) leaves the younger prefetches in flight
-  float4 grow[4];
+  // dE/dAEV row of the current centre: GR x 16 B per lane (GR = 1 covers rows of up to 256 columns, GR = 4 up to
+  // 1024), issued BEFORE this iteration's prefetch loads so that the wait for it (vmcnt counts in order) leaves the
+  // younger prefetches in flight
+  float4 grow[GR];
   const int n4 = p.aev_stride >> 2;
-  ANI_PERSISTENT_LOOP(kWavesB,
+  ANI_PERSISTENT_LOOP(kWavesB, NCH,
                       {
                         const float4* g4 = reinterpret_cast<const float4*>(a.gaev + (long long)row * p.aev_stride);
-                        _Pragma("unroll") for (int c = 0; c < 4; c++) grow[c] =
+                        _Pragma("unroll") for (int c = 0; c < GR; c++) grow[c] =
                             (cur.info.x >= 0 && lane + 64 * c < n4) ? g4[lane + 64 * c] : make_float4(0, 0, 0, 0);
                       },
-                      (backward_centre<NA, NZ>(p, a, cap, L, row, cur, grow, lane)))
+                      (backward_centre<NA, NZ, NCH, GR>(p, a, cap, L, row, cur, grow, lane)))
 }
 
 // =====================================================================================================
@@ -1016,9 +1021,9 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_generic(AevParams p,
   for (int q = lane; q < nrad; q += 64) {
     const float gx = L.gd[3 * q], gy = L.gd[3 * q + 1], gz = L.gd[3 * q + 2];
     const int j = L.j[q];
-    atomicAdd(&a.fbuf[3 * j + 0], -gx);
-    atomicAdd(&a.fbuf[3 * j + 1], -gy);
-    atomicAdd(&a.fbuf[3 * j + 2], -gz);
+    atomicAdd(&a.fbuf[4 * j + 0], -gx);
+    atomicAdd(&a.fbuf[4 * j + 1], -gy);
+    atomicAdd(&a.fbuf[4 * j + 2], -gz);
     fx += gx; fy += gy; fz += gz;
     if (a.virial) {
       const float dx = L.dx[q], dy = L.dy[q], dz = L.dz[q];
@@ -1035,9 +1040,9 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_generic(AevParams p,
   }
   const int i = a.ilist[ii];
   if (lane == 0) {
-    atomicAdd(&a.fbuf[3 * i + 0], fx);
-    atomicAdd(&a.fbuf[3 * i + 1], fy);
-    atomicAdd(&a.fbuf[3 * i + 2], fz);
+    atomicAdd(&a.fbuf[4 * i + 0], fx);
+    atomicAdd(&a.fbuf[4 * i + 1], fy);
+    atomicAdd(&a.fbuf[4 * i + 2], fz);
   }
   if (a.virial) {
 #pragma unroll
@@ -1094,6 +1099,13 @@ static int persistent_blocks(K kernel, int nrows, int waves_per_block, size_t ld
   return need < fit ? need : fit;
 }
 
+template <typename K>
+static void launch_fast(K kernel, const AevParams& p, const AevArgs& a, int waves, size_t lds, int cap, int rowf, hipStream_t st) {
+  // raising the dynamic-LDS limit is per kernel; every instantiation passes through here once
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.nrows, waves, lds)), dim3(64 * waves), lds, st, p, a, cap, rowf);
+}
+
 void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
   if (a.nrows <= 0) return;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
@@ -1102,15 +1114,11 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
     if (cap < 64) cap = 64;
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, false, rowf) * 4 * kWaves;
-    if (fast_kind(p) == 1) {
-      static bool once = ((void)hipFuncSetAttribute((const void*)aev_forward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-      (void)once;
-      hipLaunchKernelGGL((aev_forward_fast<8, 4>), dim3(persistent_blocks(aev_forward_fast<8, 4>, a.nrows, kWaves, lds)), block, lds, st, p, a, cap, rowf);
-    } else {
-      static bool once = ((void)hipFuncSetAttribute((const void*)aev_forward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-      (void)once;
-      hipLaunchKernelGGL((aev_forward_fast<4, 8>), dim3(persistent_blocks(aev_forward_fast<4, 8>, a.nrows, kWaves, lds)), block, lds, st, p, a, cap, rowf);
-    }
+    const bool k1 = fast_kind(p) == 1, n3 = max_numneigh <= 192;
+    if (k1 && n3) launch_fast(aev_forward_fast<8, 4, 3>, p, a, kWaves, lds, cap, rowf, st);
+    else if (k1) launch_fast(aev_forward_fast<8, 4, 4>, p, a, kWaves, lds, cap, rowf, st);
+    else if (n3) launch_fast(aev_forward_fast<4, 8, 3>, p, a, kWaves, lds, cap, rowf, st);
+    else launch_fast(aev_forward_fast<4, 8, 4>, p, a, kWaves, lds, cap, rowf, st);
   } else {
     hipLaunchKernelGGL(aev_forward_generic, grid, block, 0, st, p, a);
   }
@@ -1125,15 +1133,20 @@ void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
     if (cap < 64) cap = 64;
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, true, rowf) * 4 * kWavesB;
-    if (fast_kind(p) == 1) {
-      static bool once = ((void)hipFuncSetAttribute((const void*)aev_backward_fast<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-      (void)once;
-      hipLaunchKernelGGL((aev_backward_fast<8, 4>), dim3(persistent_blocks(aev_backward_fast<8, 4>, a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap, rowf);
+    const bool k1 = fast_kind(p) == 1, n3 = max_numneigh <= 192, g1 = p.aev_stride <= 256;
+#define ANI_BWD_CASE(NA, NZ, NCH, GR) launch_fast(aev_backward_fast<NA, NZ, NCH, GR>, p, a, kWavesB, lds, cap, rowf, st)
+    if (k1) {
+      if (n3 && g1) ANI_BWD_CASE(8, 4, 3, 1);
+      else if (n3) ANI_BWD_CASE(8, 4, 3, 4);
+      else if (g1) ANI_BWD_CASE(8, 4, 4, 1);
+      else ANI_BWD_CASE(8, 4, 4, 4);
     } else {
-      static bool once = ((void)hipFuncSetAttribute((const void*)aev_backward_fast<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-      (void)once;
-      hipLaunchKernelGGL((aev_backward_fast<4, 8>), dim3(persistent_blocks(aev_backward_fast<4, 8>, a.nrows, kWavesB, lds)), blockB, lds, st, p, a, cap, rowf);
+      if (n3 && g1) ANI_BWD_CASE(4, 8, 3, 1);
+      else if (n3) ANI_BWD_CASE(4, 8, 3, 4);
+      else if (g1) ANI_BWD_CASE(4, 8, 4, 1);
+      else ANI_BWD_CASE(4, 8, 4, 4);
     }
+#undef ANI_BWD_CASE
   } else {
     hipLaunchKernelGGL(aev_backward_generic, grid, block, 0, st, p, a);
   }

@@ -16,7 +16,7 @@ __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict_
   const int sp = species[i];
   const int cs = (sp >= 0 && sp < kMaxSpecies) ? cmap.m[sp] : 0;
   out[i] = make_float4((float)x[3 * i], (float)x[3 * i + 1], (float)x[3 * i + 2], __int_as_float(cs));
-  fbuf[3 * i] = 0.f; fbuf[3 * i + 1] = 0.f; fbuf[3 * i + 2] = 0.f;
+  reinterpret_cast<float4*>(fbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void finish_final_kernel(FinishArgs a) {
 __global__ void finish_force_kernel(const float* __restrict__ fbuf, int n3, double* __restrict__ f_out, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n3) return;
-  const double v = (double)fbuf[i] * 627.5094738898777;
+  const double v = (double)fbuf[4 * (i / 3) + (i % 3)] * 627.5094738898777;  // accumulators are one float4 per atom
   f_out[i] = accumulate ? f_out[i] + v : v;
 }
 
