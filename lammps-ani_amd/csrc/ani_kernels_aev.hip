@@ -347,47 +347,68 @@ __device__ __forceinline__ void stream_pair(const FastLds& L, int nbk, int t, in
   ib = e0.w + b;
 }
 
-// v[lane ^ OFF] for OFF = 1, 2, 4, 8 as DPP moves (VALU, no LDS crossbar round trip), 16 as a swizzle, 32 as a permute
+#ifdef ABL_NO_TWRITE
+#define TILE_ADD(p, v) asm volatile("" ::"v"(p), "v"(v))
+#else
+#define TILE_ADD(p, v) atomicAdd(p, v)
+#endif
+// v + v[lane ^ OFF] without an LDS round trip: OFF = 1, 2, 4, 8 as DPP moves inside a row of 16 lanes, OFF = 16 / 32
+// with the gfx950 row / half-wave swaps (both operands the same register: one result holds the even rows or the lower
+// half everywhere, the other the odd rows or the upper half)
 template <int OFF>
-__device__ __forceinline__ float lane_xor(float v) {
+__device__ __forceinline__ float xor_sum(float v) {
   const int x = __float_as_int(v);
-  int y;
   if constexpr (OFF == 1) {
-    y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    return v + __int_as_float(__builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
   } else if constexpr (OFF == 2) {
-    y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    return v + __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
   } else if constexpr (OFF == 4) {
-    y = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);  // row_shl:4 into banks 0,2
-    y = __builtin_amdgcn_update_dpp(y, x, 0x114, 0xf, 0xa, false);  // row_shr:4 into banks 1,3
+    int y = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);  // row_shl:4 into banks 0,2
+    y = __builtin_amdgcn_update_dpp(y, x, 0x114, 0xf, 0xa, false);      // row_shr:4 into banks 1,3
+    return v + __int_as_float(y);
   } else if constexpr (OFF == 8) {
-    y = __builtin_amdgcn_mov_dpp(x, 0x128, 0xf, 0xf, true);  // row_ror:8
+    return v + __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x128, 0xf, 0xf, true));  // row_ror:8
   } else if constexpr (OFF == 16) {
-    y = __builtin_amdgcn_ds_swizzle(x, 0x401F);              // bit mode: xor 0x10 within 32 lanes
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
   } else {
-    y = __shfl_xor(x, 32);
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
   }
-  return __int_as_float(y);
 }
-// one butterfly level of the tile reductions: lanes that differ in bit OFF hold the same row (OFF < TB: sum the
-// row values) or the same column (OFF >= TB: sum the column values); TB is wave-uniform
-template <int OFF, int N>
-__device__ __forceinline__ void tile_level(int TB, float (&rowv)[N], float (&colv)[N]) {
-  if (OFF < TB) {
+// Butterfly sums of a TA x TB tile (TB = 1 << TBL): the levels below TB add up the lanes of a row, the levels from TB
+// up the lanes of a column.  One straight-line instance per TB (the wave-uniform TB selects it), so no level carries
+// a branch or register copies.
+template <int TBL, int OFF, int N>
+__device__ __forceinline__ void tile_level(float (&rowv)[N], float (&colv)[N]) {
+  if constexpr (OFF < (1 << TBL)) {
 #pragma unroll
-    for (int k = 0; k < N; k++) rowv[k] += lane_xor<OFF>(rowv[k]);
+    for (int k = 0; k < N; k++) rowv[k] = xor_sum<OFF>(rowv[k]);
   } else {
 #pragma unroll
-    for (int k = 0; k < N; k++) colv[k] += lane_xor<OFF>(colv[k]);
+    for (int k = 0; k < N; k++) colv[k] = xor_sum<OFF>(colv[k]);
   }
+}
+template <int TBL, int N>
+__device__ __forceinline__ void tile_reduce_fixed(float (&rowv)[N], float (&colv)[N]) {
+  tile_level<TBL, 1, N>(rowv, colv);
+  tile_level<TBL, 2, N>(rowv, colv);
+  tile_level<TBL, 4, N>(rowv, colv);
+  tile_level<TBL, 8, N>(rowv, colv);
+  tile_level<TBL, 16, N>(rowv, colv);
+  tile_level<TBL, 32, N>(rowv, colv);
 }
 template <int N>
-__device__ __forceinline__ void tile_reduce(int TB, float (&rowv)[N], float (&colv)[N]) {
-  tile_level<1, N>(TB, rowv, colv);
-  tile_level<2, N>(TB, rowv, colv);
-  tile_level<4, N>(TB, rowv, colv);
-  tile_level<8, N>(TB, rowv, colv);
-  tile_level<16, N>(TB, rowv, colv);
-  tile_level<32, N>(TB, rowv, colv);
+__device__ __forceinline__ void tile_reduce(int tbl, float (&rowv)[N], float (&colv)[N]) {
+  switch (tbl) {
+    case 0: tile_reduce_fixed<0, N>(rowv, colv); break;
+    case 1: tile_reduce_fixed<1, N>(rowv, colv); break;
+    case 2: tile_reduce_fixed<2, N>(rowv, colv); break;
+    case 3: tile_reduce_fixed<3, N>(rowv, colv); break;
+    case 4: tile_reduce_fixed<4, N>(rowv, colv); break;
+    case 5: tile_reduce_fixed<5, N>(rowv, colv); break;
+    default: tile_reduce_fixed<6, N>(rowv, colv); break;
+  }
 }
 
 // Backward enumeration: every non-empty species-pair bucket is cut into TILES of 64 lanes laid out as
@@ -641,15 +662,19 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
 #else
   for (int tile = 0; tile < ntiles; tile++) {
 #endif
+    // everything about the tile is wave-uniform: keep it in scalar registers (the LDS loads return it per lane)
     int e = 0;
     for (int k = 1; k < nbk; k++)
-      if (tile >= L.tb[8 * k]) e = k;
+      if (tile >= __builtin_amdgcn_readfirstlane(L.tb[8 * k])) e = k;
     const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);
     const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);
-    const int a1 = e0.y, n1 = e0.z, a2 = e0.w, n2 = e1.x, outoff = e1.y, ncb = e1.w;
-    const bool tri = e1.z & 1;
-    const int tbl = e1.z >> 1, TB = 1 << tbl;
-    const int u = tile - e0.x;
+    const int a1 = __builtin_amdgcn_readfirstlane(e0.y), n1 = __builtin_amdgcn_readfirstlane(e0.z);
+    const int a2 = __builtin_amdgcn_readfirstlane(e0.w), n2 = __builtin_amdgcn_readfirstlane(e1.x);
+    const int outoff = __builtin_amdgcn_readfirstlane(e1.y), ncb = __builtin_amdgcn_readfirstlane(e1.w);
+    const int flags = __builtin_amdgcn_readfirstlane(e1.z);
+    const bool tri = flags & 1;
+    const int tbl = flags >> 1, TB = 1 << tbl;
+    const int u = tile - __builtin_amdgcn_readfirstlane(e0.x);
     const int rb = ncb > 1 ? u / ncb : u;
     const int cb = u - rb * ncb;
     const int col = (cb << 6) + (lane & (TB - 1));
@@ -731,12 +756,12 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     // within an instruction, so no conflict serialisation): a read-add-write would stall on every LDS round trip.
     const bool row_writer = (lane & (TB - 1)) == 0, col_writer = (lane >> tbl) == 0;
     if (!tri) {
-      tile_reduce<3>(TB, va, vb);
+      tile_reduce<3>(tbl, va, vb);
       if (row_writer && r < n1) {
-        atomicAdd(&L.gd[3 * qr0], va[0]); atomicAdd(&L.gd[3 * qr0 + 1], va[1]); atomicAdd(&L.gd[3 * qr0 + 2], va[2]);
+        TILE_ADD(&L.gd[3 * qr0], va[0]); TILE_ADD(&L.gd[3 * qr0 + 1], va[1]); TILE_ADD(&L.gd[3 * qr0 + 2], va[2]);
       }
       if (col_writer && col < n2) {
-        atomicAdd(&L.gd[3 * qc0], vb[0]); atomicAdd(&L.gd[3 * qc0 + 1], vb[1]); atomicAdd(&L.gd[3 * qc0 + 2], vb[2]);
+        TILE_ADD(&L.gd[3 * qc0], vb[0]); TILE_ADD(&L.gd[3 * qc0 + 1], vb[1]); TILE_ADD(&L.gd[3 * qc0 + 2], vb[2]);
       }
     } else {
       // lanes above the diagonal: ia = r, ib = col; lanes below: ia = nn-1-r, ib = nn-1-col
@@ -746,20 +771,20 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
         rw[k] = above ? va[k] : 0.f; rw[3 + k] = above ? 0.f : va[k];
         cw[k] = above ? vb[k] : 0.f; cw[3 + k] = above ? 0.f : vb[k];
       }
-      tile_reduce<6>(TB, rw, cw);
+      tile_reduce<6>(tbl, rw, cw);
       const bool rok = row_writer && r < (nn >> 1);
       if (rok && r < n1) {
-        atomicAdd(&L.gd[3 * qr0], rw[0]); atomicAdd(&L.gd[3 * qr0 + 1], rw[1]); atomicAdd(&L.gd[3 * qr0 + 2], rw[2]);
+        TILE_ADD(&L.gd[3 * qr0], rw[0]); TILE_ADD(&L.gd[3 * qr0 + 1], rw[1]); TILE_ADD(&L.gd[3 * qr0 + 2], rw[2]);
       }
       if (rok && nn - 1 - r < n1) {
-        atomicAdd(&L.gd[3 * qr1], rw[3]); atomicAdd(&L.gd[3 * qr1 + 1], rw[4]); atomicAdd(&L.gd[3 * qr1 + 2], rw[5]);
+        TILE_ADD(&L.gd[3 * qr1], rw[3]); TILE_ADD(&L.gd[3 * qr1 + 1], rw[4]); TILE_ADD(&L.gd[3 * qr1 + 2], rw[5]);
       }
       const bool cok = col_writer && col < nn;
       if (cok && col < n1) {
-        atomicAdd(&L.gd[3 * qc0], cw[0]); atomicAdd(&L.gd[3 * qc0 + 1], cw[1]); atomicAdd(&L.gd[3 * qc0 + 2], cw[2]);
+        TILE_ADD(&L.gd[3 * qc0], cw[0]); TILE_ADD(&L.gd[3 * qc0 + 1], cw[1]); TILE_ADD(&L.gd[3 * qc0 + 2], cw[2]);
       }
       if (cok && nn - 1 - col < n1) {
-        atomicAdd(&L.gd[3 * qc1], cw[3]); atomicAdd(&L.gd[3 * qc1 + 1], cw[4]); atomicAdd(&L.gd[3 * qc1 + 2], cw[5]);
+        TILE_ADD(&L.gd[3 * qc1], cw[3]); TILE_ADD(&L.gd[3 * qc1 + 1], cw[4]); TILE_ADD(&L.gd[3 * qc1 + 2], cw[5]);
       }
     }
 #else
@@ -1127,7 +1152,6 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
 void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
   if (a.nrows <= 0) return;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
-  const dim3 gridB((a.nrows + kWavesB - 1) / kWavesB), blockB(64 * kWavesB);
   if (aev_fast_path(p, max_numneigh)) {
     int cap = (max_numneigh + 63) / 64 * 64;
     if (cap < 64) cap = 64;
