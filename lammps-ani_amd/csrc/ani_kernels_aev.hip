@@ -376,87 +376,56 @@ __device__ __forceinline__ float xor_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
   }
 }
-// Butterfly sums of a TA x TB tile (TB = 1 << TBL): the levels below TB add up the lanes of a row, the levels from TB
-// up the lanes of a column.  One straight-line instance per TB (the wave-uniform TB selects it), so no level carries
-// a branch or register copies.
-template <int TBL, int OFF, int N>
-__device__ __forceinline__ void tile_level(float (&rowv)[N], float (&colv)[N]) {
-  if constexpr (OFF < (1 << TBL)) {
-#pragma unroll
-    for (int k = 0; k < N; k++) rowv[k] = xor_sum<OFF>(rowv[k]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < N; k++) colv[k] = xor_sum<OFF>(colv[k]);
-  }
-}
-template <int TBL, int N>
-__device__ __forceinline__ void tile_reduce_fixed(float (&rowv)[N], float (&colv)[N]) {
-  tile_level<TBL, 1, N>(rowv, colv);
-  tile_level<TBL, 2, N>(rowv, colv);
-  tile_level<TBL, 4, N>(rowv, colv);
-  tile_level<TBL, 8, N>(rowv, colv);
-  tile_level<TBL, 16, N>(rowv, colv);
-  tile_level<TBL, 32, N>(rowv, colv);
-}
-template <int N>
-__device__ __forceinline__ void tile_reduce(int tbl, float (&rowv)[N], float (&colv)[N]) {
-  switch (tbl) {
-    case 0: tile_reduce_fixed<0, N>(rowv, colv); break;
-    case 1: tile_reduce_fixed<1, N>(rowv, colv); break;
-    case 2: tile_reduce_fixed<2, N>(rowv, colv); break;
-    case 3: tile_reduce_fixed<3, N>(rowv, colv); break;
-    case 4: tile_reduce_fixed<4, N>(rowv, colv); break;
-    case 5: tile_reduce_fixed<5, N>(rowv, colv); break;
-    default: tile_reduce_fixed<6, N>(rowv, colv); break;
-  }
-}
-
-// Backward enumeration: every non-empty species-pair bucket is cut into TILES of 64 lanes laid out as
-// TA rows x TB columns (TB = 2^k >= the column count, capped at 64; TA = 64 / TB).
-//   s1 != s2 : row = neighbour of species s1, column = neighbour of species s2 (n1 x n2 rectangle);
+// Backward enumeration.  Every non-empty species-pair bucket is laid out as ROWS of 16 lanes (one DPP row each):
+//   s1 != s2 : row = neighbour of the species with fewer neighbours, column = neighbour of the other species;
 //   s1 == s2 : the strict upper triangle of n x n folded into nn/2 rows x nn columns (nn = n rounded up to even):
-//              lane (r, c) holds the pair (r, c) if c > r and the pair (nn-1-r, nn-1-c) if c < r.
-// With that layout the per-neighbour sums of the pair gradients are sums along rows / along columns, i.e. a few
-// xor-shuffles and one plain LDS add per neighbour, instead of six LDS float atomics per pair with ~10-way address
-// conflicts (which cost more than all the arithmetic of the pass).
-// entry: {tile0, a1, n1, a2, n2, outoff, tri | log2(TB) << 1, column blocks}.  Returns the number of tiles.
+//              lane (r, c) holds the pair (r, c) if c > r and the pair (nn-1-r, nn-1-c) if c < r;
+//   more than 16 columns: the row is cut into column blocks of 16, each its own row of the stream.
+// The rows of all buckets form one stream; a step of the pair loop takes 4 consecutive rows (64 lanes), whatever
+// buckets they belong to.  A pair's gradient with respect to its ROW neighbour is summed over the row with four DPP
+// adds (no LDS), lane 0 of the row adds the sum to that neighbour's LDS accumulator; the gradient with respect to the
+// COLUMN neighbour goes to its accumulator with one LDS float add per lane (at most ~4 lanes of an instruction
+// share an address).  The first version of this pass issued six LDS float atomics per pair with ~10-way address
+// conflicts, which cost more than all of its arithmetic.
+// entry: {row0, ra, nr, ca, nc, outoff, tri, column blocks}.  Returns the number of rows in the stream.
 template <int NA, int NZ>
-__device__ __forceinline__ int build_tile_table(const AevParams& p, int lane, FastLds& L, int& nbk) {
+__device__ __forceinline__ int build_row_table(const AevParams& p, int lane, FastLds& L, int& nbk) {
   const int nb_all = p.S * (p.S + 1) / 2;
-  int s1 = 0, s2 = 0, n1 = 0, n2 = 0, ntile = 0, tbl = 0, ncb = 1, tri = 0;
+  int s1 = 0, s2 = 0, ra = 0, nr = 0, ca = 0, nc = 0, nrow = 0, ncb = 1, tri = 0;
   if (lane < nb_all) {
     int rem = lane;
     while (rem >= p.S - s1) { rem -= p.S - s1; s1++; }
     s2 = s1 + rem;
-    n1 = L.astart[s1 + 1] - L.astart[s1];
-    n2 = L.astart[s2 + 1] - L.astart[s2];
+    const int a1 = L.astart[s1], a2 = L.astart[s2];
+    const int n1 = L.astart[s1 + 1] - a1, n2 = L.astart[s2 + 1] - a2;
     int nrows = 0, ncols = 0;
     if (s1 == s2) {
       tri = 1;
+      ra = ca = a1; nr = nc = n1;
       const int nn = (n1 + 1) & ~1;
       if (n1 >= 2) { nrows = nn >> 1; ncols = nn; }
     } else if (n1 > 0 && n2 > 0) {
-      nrows = n1; ncols = n2;
+      const bool sw = n1 > n2;   // fewer rows, wider rows
+      ra = sw ? a2 : a1; nr = sw ? n2 : n1;
+      ca = sw ? a1 : a2; nc = sw ? n1 : n2;
+      nrows = nr; ncols = nc;
     }
     if (nrows > 0) {
-      const int cw = min(ncols, 64);
-      tbl = 32 - __clz(cw - 1);  // log2 of the next power of two (cw = 1 -> 0)
-      ncb = (ncols + 63) >> 6;
-      const int TA = 64 >> tbl;
-      ntile = ((nrows + TA - 1) / TA) * ncb;
+      ncb = (ncols + 15) >> 4;
+      nrow = nrows * ncb;
     }
   }
-  int incl = ntile;
+  int incl = nrow;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int t = __shfl_up(incl, off);
     if (lane >= off) incl += t;
   }
-  const unsigned long long m = __ballot(ntile > 0);
-  if (ntile > 0) {
+  const unsigned long long m = __ballot(nrow > 0);
+  if (nrow > 0) {
     int* e = L.tb + 8 * lanes_below(m);
-    e[0] = incl - ntile; e[1] = L.astart[s1]; e[2] = n1; e[3] = L.astart[s2]; e[4] = n2;
-    e[5] = p.radial_len + lane * (NA * NZ); e[6] = tri | (tbl << 1); e[7] = ncb;
+    e[0] = incl - nrow; e[1] = ra; e[2] = nr; e[3] = ca; e[4] = nc;
+    e[5] = p.radial_len + lane * (NA * NZ); e[6] = tri; e[7] = ncb;
   }
   nbk = __popcll(m);
   return __shfl(incl, 63);
@@ -651,49 +620,35 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     }
   }
   int nbk;
-  const int ntiles = build_tile_table<NA, NZ>(p, lane, L, nbk);
+  const int nrows_stream = build_row_table<NA, NZ>(p, lane, L, nbk);
   wave_sync();
 
-  // ---- angular: lane = pair of a TA x TB tile (see build_tile_table) ----
+  // ---- angular: lane = pair; 4 rows of the stream per step (see build_row_table) ----
   const float cA = -p.EtaA * kLog2e;
   const float revA = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
 #ifdef ABL_NO_ANG
-  for (int tile = 0; tile < 0; tile++) {
+  for (int R0 = 0; R0 < 0; R0 += 4) {
 #else
-  for (int tile = 0; tile < ntiles; tile++) {
+  for (int R0 = 0; R0 < nrows_stream; R0 += 4) {
 #endif
-    // everything about the tile is wave-uniform: keep it in scalar registers (the LDS loads return it per lane)
+    const int R = R0 + (lane >> 4);
+    const bool row_ok = R < nrows_stream;
     int e = 0;
     for (int k = 1; k < nbk; k++)
-      if (tile >= __builtin_amdgcn_readfirstlane(L.tb[8 * k])) e = k;
-    const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);
-    const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);
-    const int a1 = __builtin_amdgcn_readfirstlane(e0.y), n1 = __builtin_amdgcn_readfirstlane(e0.z);
-    const int a2 = __builtin_amdgcn_readfirstlane(e0.w), n2 = __builtin_amdgcn_readfirstlane(e1.x);
-    const int outoff = __builtin_amdgcn_readfirstlane(e1.y), ncb = __builtin_amdgcn_readfirstlane(e1.w);
-    const int flags = __builtin_amdgcn_readfirstlane(e1.z);
-    const bool tri = flags & 1;
-    const int tbl = flags >> 1, TB = 1 << tbl;
-    const int u = tile - __builtin_amdgcn_readfirstlane(e0.x);
-    const int rb = ncb > 1 ? u / ncb : u;
-    const int cb = u - rb * ncb;
-    const int col = (cb << 6) + (lane & (TB - 1));
-    const int r = rb * (64 >> tbl) + (lane >> tbl);
-    const int nn = (n1 + 1) & ~1;
-    const bool above = col > r;  // tri only: which of the two folded pairs this lane holds
-    bool valid;
-    int ia, ib;
-    if (tri) {
-      const int a = above ? r : nn - 1 - r;
-      const int b = above ? col : nn - 1 - col;
-      valid = col != r && r < (nn >> 1) && col < nn && b < n1;
-      ia = a1 + (valid ? a : 0);
-      ib = a1 + (valid ? b : 1);   // distinct neighbours keep the masked geometry finite
-    } else {
-      valid = r < n1 && col < n2;
-      ia = a1 + (valid ? r : 0);
-      ib = a2 + (valid ? col : 0);
-    }
+      if (R >= L.tb[8 * k]) e = k;
+    const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);   // row0, ra, nr, ca
+    const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);   // nc, outoff, tri, ncb
+    const bool tri = e1.z != 0;
+    const int u = R - e0.x;
+    const int r = e1.w > 1 ? u / e1.w : u;
+    const int col = ((u - r * e1.w) << 4) + (lane & 15);
+    const int nn = (e0.z + 1) & ~1;
+    const bool above = !tri || col > r;   // tri: which of the two folded pairs this lane holds
+    const int a = above ? r : nn - 1 - r;
+    const int b = above ? col : nn - 1 - col;
+    const bool valid = row_ok && b < e1.x && (!tri || col != r);
+    const int ia = e0.y + (valid ? a : 0);
+    const int ib = e0.w + (valid ? b : (tri ? 1 : 0));   // masked lanes: distinct neighbours keep the geometry finite
     const float4 A = L.ad[ia], B = L.ad[ib];
     const float inv_ra = frcp(A.w), inv_rb = frcp(B.w);
     const float inv_rr = inv_ra * inv_rb;
@@ -714,7 +669,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       f1[z] = pm1 * bz;
       df1[z] = p.Zeta * pm1 * 0.5f * (sn * p.cosZ[z] - c * p.sinZ[z]) * inv_s;
     }
-    const float4* gg4 = reinterpret_cast<const float4*>(L.row + outoff);  // outoff is a multiple of NA*NZ
+    const float4* gg4 = reinterpret_cast<const float4*>(L.row + e1.y);  // outoff is a multiple of NA*NZ
     float Aq = 0.f, Bq = 0.f, Cq = 0.f;
 #pragma unroll
     for (int sa = 0; sa < NA; sa++) {
@@ -739,52 +694,32 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     Aq *= 2.f * P * 0.95f;
     Bq *= P;       // 2 * P * 0.5
     Cq *= valid ? 2.f : 0.f;
-    const float ca = Aq * inv_rr;
+    const float cc = Aq * inv_rr;
     const float ta = (Bq + Cq * dfa * fb) * inv_ra - Aq * cosv * inv_ra * inv_ra;
     const float tb = (Bq + Cq * fa * dfb) * inv_rb - Aq * cosv * inv_rb * inv_rb;
-    float va[3] = {ca * B.x + ta * A.x, ca * B.y + ta * A.y, ca * B.z + ta * A.z};  // d/d(neighbour ia)
-    float vb[3] = {ca * A.x + tb * B.x, ca * A.y + tb * B.y, ca * A.z + tb * B.z};  // d/d(neighbour ib)
+    const float va[3] = {cc * B.x + ta * A.x, cc * B.y + ta * A.y, cc * B.z + ta * A.z};  // d/d(neighbour ia)
+    const float vb[3] = {cc * A.x + tb * B.x, cc * A.y + tb * B.y, cc * A.z + tb * B.z};  // d/d(neighbour ib)
 #ifndef ABL_NO_LATOM
-    // radial-list slots of the neighbours this lane may have to update (the reads overlap the butterflies below)
-    const int cbase = tri ? a1 : a2, cmax = (tri ? n1 : n2) - 1;
-    const int qr0 = L.aidx[a1 + min(r, n1 - 1)];
-    const int qc0 = L.aidx[cbase + min(col, cmax)];
-    const int qr1 = tri ? L.aidx[a1 + min(max(nn - 1 - r, 0), n1 - 1)] : 0;
-    const int qc1 = tri ? L.aidx[a1 + min(max(nn - 1 - col, 0), n1 - 1)] : 0;
-    // Sums along rows (lanes sharing ia) and along columns (lanes sharing ib), then ONE lane per neighbour adds the
-    // sum to its LDS accumulator.  Those adds are LDS atomics only to make them fire-and-forget (distinct addresses
-    // within an instruction, so no conflict serialisation): a read-add-write would stall on every LDS round trip.
-    const bool row_writer = (lane & (TB - 1)) == 0, col_writer = (lane >> tbl) == 0;
-    if (!tri) {
-      tile_reduce<3>(tbl, va, vb);
-      if (row_writer && r < n1) {
-        TILE_ADD(&L.gd[3 * qr0], va[0]); TILE_ADD(&L.gd[3 * qr0 + 1], va[1]); TILE_ADD(&L.gd[3 * qr0 + 2], va[2]);
-      }
-      if (col_writer && col < n2) {
-        TILE_ADD(&L.gd[3 * qc0], vb[0]); TILE_ADD(&L.gd[3 * qc0 + 1], vb[1]); TILE_ADD(&L.gd[3 * qc0 + 2], vb[2]);
-      }
-    } else {
-      // lanes above the diagonal: ia = r, ib = col; lanes below: ia = nn-1-r, ib = nn-1-col
-      float rw[6], cw[6];   // [0..2] above-diagonal part, [3..5] below
+    // column neighbour: one LDS add per lane and component
+    if (valid) {
+      const int qb = L.aidx[ib];
+      TILE_ADD(&L.gd[3 * qb], vb[0]); TILE_ADD(&L.gd[3 * qb + 1], vb[1]); TILE_ADD(&L.gd[3 * qb + 2], vb[2]);
+    }
+    // row neighbour(s): sums over the 16 lanes of the row, [0..2] for the pairs whose ia is r (all pairs of a
+    // rectangular bucket, the above-diagonal ones of a folded triangle), [3..5] for those whose ia is nn-1-r
+    float rw[6];
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        rw[k] = above ? va[k] : 0.f; rw[3 + k] = above ? 0.f : va[k];
-        cw[k] = above ? vb[k] : 0.f; cw[3 + k] = above ? 0.f : vb[k];
+    for (int k = 0; k < 3; k++) { rw[k] = above ? va[k] : 0.f; rw[3 + k] = above ? 0.f : va[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) rw[k] = xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(rw[k]))));
+    if ((lane & 15) == 0 && row_ok) {
+      if (r < e0.z) {
+        const int q = L.aidx[e0.y + r];
+        TILE_ADD(&L.gd[3 * q], rw[0]); TILE_ADD(&L.gd[3 * q + 1], rw[1]); TILE_ADD(&L.gd[3 * q + 2], rw[2]);
       }
-      tile_reduce<6>(tbl, rw, cw);
-      const bool rok = row_writer && r < (nn >> 1);
-      if (rok && r < n1) {
-        TILE_ADD(&L.gd[3 * qr0], rw[0]); TILE_ADD(&L.gd[3 * qr0 + 1], rw[1]); TILE_ADD(&L.gd[3 * qr0 + 2], rw[2]);
-      }
-      if (rok && nn - 1 - r < n1) {
-        TILE_ADD(&L.gd[3 * qr1], rw[3]); TILE_ADD(&L.gd[3 * qr1 + 1], rw[4]); TILE_ADD(&L.gd[3 * qr1 + 2], rw[5]);
-      }
-      const bool cok = col_writer && col < nn;
-      if (cok && col < n1) {
-        TILE_ADD(&L.gd[3 * qc0], cw[0]); TILE_ADD(&L.gd[3 * qc0 + 1], cw[1]); TILE_ADD(&L.gd[3 * qc0 + 2], cw[2]);
-      }
-      if (cok && nn - 1 - col < n1) {
-        TILE_ADD(&L.gd[3 * qc1], cw[3]); TILE_ADD(&L.gd[3 * qc1 + 1], cw[4]); TILE_ADD(&L.gd[3 * qc1 + 2], cw[5]);
+      if (tri && nn - 1 - r < e0.z) {
+        const int q = L.aidx[e0.y + nn - 1 - r];
+        TILE_ADD(&L.gd[3 * q], rw[3]); TILE_ADD(&L.gd[3 * q + 1], rw[4]); TILE_ADD(&L.gd[3 * q + 2], rw[5]);
       }
     }
 #else
