@@ -149,6 +149,10 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *       nor as neighbour) are identically zero; with 1 the kernels work on the remaining columns only (ANI-2x water:
  *       128 of 1008) and the first-layer products use the matching weight columns — the same sums without the zero
  *       terms.  0 forces the full 1008-column layout.
+ *   "full_radial_capacity" (default 0): with the radial screen at Rcr (use_cuaev = 1) the kernels reserve LDS for 3/4
+ *       of the longest neighbour list (>= 128 entries) per centre -- a uniform 7.1 A list holds 37 % of its entries
+ *       inside 5.1 A -- instead of all of it; a centre that needs more raises ANI_ERR_CAPACITY.  1 reserves the full
+ *       list length (takes effect at the next call).
  */
 int ani_set_option(ani_handle* h, const char* name, int value);
 /* copy `bytes` from a device pointer of the view to host memory (synchronises the handle's stream first) */

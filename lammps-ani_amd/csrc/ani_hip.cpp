@@ -205,6 +205,7 @@ int upload_model(ani_handle* h) {
   p.S = m.S; p.nR = m.nR; p.nA = m.nA; p.nZ = m.nZ; p.nAZ = m.nA * m.nZ;
   p.radial_len = m.radial_len; p.aev_len = m.aev_len; p.aev_stride = aev_stride;
   p.compat = h->use_cuaev ? 0 : 1;
+  p.full_cap = 0;
   p.Rcr = (float)m.Rcr; p.Rca = (float)m.Rca; p.EtaR = (float)m.EtaR; p.EtaA = (float)m.EtaA; p.Zeta = (float)m.Zeta;
   p.pi_over_Rcr = (float)(M_PI / m.Rcr); p.pi_over_Rca = (float)(M_PI / m.Rca);
   for (int k = 0; k < m.nR; k++) p.ShfR[k] = (float)m.ShfR[k];
@@ -596,8 +597,8 @@ int finish_host(ani_handle* h, int ntotal, int nlocal, int eflag_atom, int vflag
   HIP_TRY(h, hipStreamSynchronize(st));
   if (flag) {
     HIP_TRY(h, hipMemsetAsync(h->err_flag.p, 0, sizeof(int), st));
-    h->err = "an atom has more neighbours inside the radial/angular cutoff than the kernels' LDS capacity (" +
-             std::to_string(kMaxRad) + "/" + std::to_string(kMaxAng) + ")";
+    h->err = "an atom has more neighbours inside the radial/angular cutoff than the kernels' LDS capacity (radial: the "
+             "longest list, or 3/4 of it unless option full_radial_capacity is set; angular: " + std::to_string(kMaxAng) + ")";
     return ANI_ERR_CAPACITY;
   }
   if (out_energy) *out_energy = ev[0];
@@ -860,6 +861,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
     h->prune = value != 0;
     h->have_list = false;  // takes effect at the next rebuild (ago = 0), which the caller must issue
     h->active_mask = -1;
+    return ANI_OK;
+  }
+  if (strcmp(name, "full_radial_capacity") == 0) {
+    h->ap.full_cap = h->ap_run.full_cap = value != 0;
     return ANI_OK;
   }
   h->err = std::string("unknown option '") + name + "'";

@@ -1025,11 +1025,25 @@ static int fast_kind(const AevParams& p) {
   return 0;
 }
 
+// Capacity of the per-centre radial list in LDS.  pyaev semantics keep every list entry, so the longest list decides.
+// With the radial screen at Rcr only the entries inside Rcr are kept -- for the reference's settings (5.1 A inside a
+// 7.1 A list) 37 % of a uniform neighbourhood -- so 3/4 of the longest list (at least 128 slots) is reserved instead of
+// all of it; the smaller LDS slice is what lets more waves share a CU.  A centre that still overflows raises the
+// capacity error like any other overflow (never a silent truncation), and AevParams::full_cap restores the full size.
+static int radial_cap(const AevParams& p, int max_numneigh) {
+  int full = (max_numneigh + 63) / 64 * 64;
+  if (full < 64) full = 64;
+  if (p.compat || p.full_cap) return full;
+  int est = (3 * max_numneigh + 3) / 4;
+  if (est < 128) est = 128;
+  est = (est + 63) / 64 * 64;
+  return est < full ? est : full;
+}
+
 bool aev_fast_path(const AevParams& p, int max_numneigh) {
   if (!fast_kind(p)) return false;
-  const int cap = (max_numneigh + 63) / 64 * 64;
   // a backward workgroup (kWavesB slices) and a forward workgroup (kWaves slices) must each fit in 160 KB
-  const int c = cap < 64 ? 64 : cap;
+  const int c = radial_cap(p, max_numneigh);
   return (size_t)fast_wave_floats(c, true) * 4 * kWavesB <= 160 * 1024 && (size_t)fast_wave_floats(c, false) * 4 * kWaves <= 160 * 1024;
 }
 
@@ -1070,8 +1084,7 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
   if (a.nrows <= 0) return;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
   if (aev_fast_path(p, max_numneigh)) {
-    int cap = (max_numneigh + 63) / 64 * 64;
-    if (cap < 64) cap = 64;
+    const int cap = radial_cap(p, max_numneigh);
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, false, rowf) * 4 * kWaves;
     const bool k1 = fast_kind(p) == 1, n3 = max_numneigh <= 192;
@@ -1088,8 +1101,7 @@ void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
   if (a.nrows <= 0) return;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
   if (aev_fast_path(p, max_numneigh)) {
-    int cap = (max_numneigh + 63) / 64 * 64;
-    if (cap < 64) cap = 64;
+    const int cap = radial_cap(p, max_numneigh);
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, true, rowf) * 4 * kWavesB;
     const bool k1 = fast_kind(p) == 1, n3 = max_numneigh <= 192, g1 = p.aev_stride <= 256;

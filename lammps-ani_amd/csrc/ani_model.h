@@ -34,6 +34,7 @@ std::string load_model(const std::string& path, int use_num_models, HostModel& o
 struct AevParams {
   int S, nR, nA, nZ, nAZ, radial_len, aev_len, aev_stride;
   int compat;  // 1: no radial screening ("pyaev"), 0: r <= Rcr ("cuaev")
+  int full_cap;  // 1: size the radial LDS list for the longest neighbour list even when screened (ani_set_option)
   float Rcr, Rca, EtaR, EtaA, Zeta, pi_over_Rcr, pi_over_Rca;
   float ShfR[kMaxShfR], ShfA[kMaxShfA], cosZ[kMaxShfZ], sinZ[kMaxShfZ];
 };
