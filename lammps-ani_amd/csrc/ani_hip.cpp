@@ -63,6 +63,9 @@ struct SpeciesNet {
   // double-precision mirrors of the above (precision 'double' only)
   std::vector<double*> W64, b64, WT64;
   double *W0c64 = nullptr, *WT0c64 = nullptr, *w_out64 = nullptr, *b_out64 = nullptr;
+  // three-way bf16 splits of W / WT / W0c / WT0c for the split-bf16 MFMA path (blocked [N][ceil(K/16)][3][16])
+  std::vector<unsigned short*> W3, WT3;
+  unsigned short *W0c3 = nullptr, *WT0c3 = nullptr;
 };
 
 }  // namespace
@@ -74,6 +77,7 @@ struct ani_handle {
   SpeciesMap cmap{};  // species -> index among the species present
   int active_mask = -1;
   bool prune = true;  // ani_set_option("prune_absent_species")
+  bool mlp_split = true;  // ani_set_option("mlp_split_bf16"): six bf16 MFMA products per fp32 product instead of fp32-input MFMA
   std::vector<int> colmap;  // ap_run column -> ap column
   int device = 0;
   bool use_cuaev = true, use_fullnbr = true, use_single = true;
@@ -141,6 +145,15 @@ int mirror64(ani_handle* h, double** dst, const float* src, size_t n) {
   return ANI_OK;
 }
 
+// device copy of `batch` matrices [N][ld] (first K columns) as blocked bf16 hi/mid/lo planes
+int make_split(ani_handle* h, unsigned short** dst, const float* src, int batch, long long s_src, int N, int K, int ld) {
+  const size_t elems = split_bf16x3_elems(N, K) * (size_t)batch;
+  HIP_TRY(h, hipMalloc((void**)dst, std::max<size_t>(elems, 1) * sizeof(unsigned short)));
+  launch_split_bf16x3(src, batch, s_src, N, K, ld, *dst, nullptr);
+  HIP_TRY(h, hipDeviceSynchronize());
+  return ANI_OK;
+}
+
 int upload_model(ani_handle* h) {
   const HostModel& m = h->model;
   const int L = m.L, M = m.M;
@@ -155,6 +168,7 @@ int upload_model(ani_handle* h) {
     if (d[L - 1] > 256) { h->err = "last hidden layer wider than 256 is not supported"; return ANI_ERR_MODEL; }
     n.W.assign(L - 1, nullptr); n.b.assign(L - 1, nullptr); n.WT.assign(L - 1, nullptr);
     n.W64.assign(L - 1, nullptr); n.b64.assign(L - 1, nullptr); n.WT64.assign(L - 1, nullptr);
+    n.W3.assign(L - 1, nullptr); n.WT3.assign(L - 1, nullptr);
     for (int k = 0; k < L - 1; k++) {
       const int out = d[k + 1], in = d[k], kp = n.w[k];
       std::vector<float> W((size_t)M * out * kp, 0.f), b((size_t)M * out);
@@ -168,6 +182,7 @@ int upload_model(ani_handle* h) {
       rc = upload(h, &n.b[k], b); if (rc) return rc;
       rc = mirror64(h, &n.W64[k], n.W[k], W.size()); if (rc) return rc;
       rc = mirror64(h, &n.b64[k], n.b[k], b.size()); if (rc) return rc;
+      rc = make_split(h, &n.W3[k], n.W[k], M, (long long)out * kp, out, kp, kp); if (rc) return rc;
       // transposed copies for the backward products
       if (k == 0) {
         const int w1 = n.w[1];
@@ -177,6 +192,7 @@ int upload_model(ani_handle* h) {
             for (int i = 0; i < in; i++) T[(size_t)i * M * w1 + (size_t)a * w1 + o] = m.W[a][s][0][(size_t)o * in + i];
         rc = upload(h, &n.WT[0], T); if (rc) return rc;
         rc = mirror64(h, &n.WT64[0], n.WT[0], T.size()); if (rc) return rc;
+        rc = make_split(h, &n.WT3[0], n.WT[0], 1, 0, m.aev_len, M * w1, M * w1); if (rc) return rc;
       } else {
         const int wk1 = n.w[k + 1 < L ? k + 1 : k];  // K of the backward product through layer k = padded d[k+1]
         std::vector<float> T((size_t)M * in * wk1, 0.f);         // [M][d[k]][w(k+1)]
@@ -185,6 +201,7 @@ int upload_model(ani_handle* h) {
             for (int i = 0; i < in; i++) T[((size_t)a * in + i) * wk1 + o] = m.W[a][s][k][(size_t)o * in + i];
         rc = upload(h, &n.WT[k], T); if (rc) return rc;
         rc = mirror64(h, &n.WT64[k], n.WT[k], T.size()); if (rc) return rc;
+        rc = make_split(h, &n.WT3[k], n.WT[k], M, (long long)in * wk1, in, wk1, wk1); if (rc) return rc;
       }
     }
     {  // output layer
@@ -229,8 +246,11 @@ int specialize(ani_handle* h, int mask) {
     if (n.WT0c) (void)hipFree(n.WT0c);
     if (n.W0c64) (void)hipFree(n.W0c64);
     if (n.WT0c64) (void)hipFree(n.WT0c64);
+    if (n.W0c3) (void)hipFree(n.W0c3);
+    if (n.WT0c3) (void)hipFree(n.WT0c3);
     n.W0c = n.WT0c = nullptr;
     n.W0c64 = n.WT0c64 = nullptr;
+    n.W0c3 = n.WT0c3 = nullptr;
   }
   std::vector<int> act;
   for (int s = 0; s < m.S; s++) {
@@ -280,6 +300,8 @@ int specialize(ani_handle* h, int mask) {
     rc = upload(h, &n.WT0c, T); if (rc) return rc;
     rc = mirror64(h, &n.W0c64, n.W0c, W.size()); if (rc) return rc;
     rc = mirror64(h, &n.WT0c64, n.WT0c, T.size()); if (rc) return rc;
+    rc = make_split(h, &n.W0c3, n.W0c, M, (long long)out * astride, out, astride, astride); if (rc) return rc;
+    rc = make_split(h, &n.WT0c3, n.WT0c, 1, 0, alen, M * w1, M * w1); if (rc) return rc;
   }
   return ANI_OK;
 }
@@ -390,11 +412,14 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
         const int ka = h->ap_run.aev_stride;  // first layer over the AEV columns of the species present
         g.A = h->aev.p + (size_t)h->row_start[s] * ka; g.lda = ka; g.sA = 0;
         g.K = ka; g.Bt = n.W0c ? n.W0c : n.W[0]; g.ldb = ka; g.sB = (long long)d[1] * ka;
+        g.Bt3 = n.W0c ? n.W0c3 : n.W3[0];
       } else {
         g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k];
         g.K = n.w[k]; g.Bt = n.W[k]; g.ldb = n.w[k]; g.sB = (long long)d[k + 1] * n.w[k];
+        g.Bt3 = n.W3[k];
       }
       g.N = d[k + 1];
+      g.kb3 = (g.K + 15) / 16; g.sB3 = (long long)split_bf16x3_elems(g.N, g.K);
       g.bias = n.b[k]; g.sBias = d[k + 1];
       g.C = h->Hbuf[s][k + 1]; g.ldc = M * n.w[k + 1]; g.sC = n.w[k + 1];
       if (k == L - 2) {
@@ -404,7 +429,7 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
       }
       probs.push_back(g);
     }
-    launch_gemm_group(probs.data(), (int)probs.size(), k == L - 2 ? EPI_LAST : EPI_CELU, st);
+    launch_gemm_group(probs.data(), (int)probs.size(), k == L - 2 ? EPI_LAST : EPI_CELU, st, h->mlp_split);
   }
   // backward: G_{k-1} = (G_k W[k-1]) * celu'(z_{k-1}), in place over H_{k-1}
   for (int k = L - 1; k >= 2; k--) {
@@ -417,11 +442,12 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
       g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k]; g.K = n.w[k];
       g.Bt = n.WT[k - 1]; g.ldb = n.w[k]; g.sB = (long long)d[k - 1] * n.w[k];
       g.N = d[k - 1];
+      g.Bt3 = n.WT3[k - 1]; g.kb3 = (g.K + 15) / 16; g.sB3 = (long long)split_bf16x3_elems(g.N, g.K);
       g.aux = h->Hbuf[s][k - 1]; g.ldaux = M * n.w[k - 1]; g.sAux = n.w[k - 1];
       g.C = h->Hbuf[s][k - 1]; g.ldc = M * n.w[k - 1]; g.sC = n.w[k - 1];
       probs.push_back(g);
     }
-    launch_gemm_group(probs.data(), (int)probs.size(), EPI_BWD, st);
+    launch_gemm_group(probs.data(), (int)probs.size(), EPI_BWD, st, h->mlp_split);
   }
   // dE/dAEV = sum over members of G_1 W[0]  (members concatenated along K)
   probs.clear();
@@ -433,10 +459,11 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
     g.A = h->Hbuf[s][1]; g.lda = M * n.w[1]; g.K = M * n.w[1];
     g.Bt = n.WT0c ? n.WT0c : n.WT[0]; g.ldb = M * n.w[1];
     g.N = h->ap_run.aev_len;
+    g.Bt3 = n.WT0c ? n.WT0c3 : n.WT3[0]; g.kb3 = (g.K + 15) / 16; g.sB3 = 0;
     g.C = h->gaev.p + (size_t)h->row_start[s] * h->ap_run.aev_stride; g.ldc = h->ap_run.aev_stride;
     probs.push_back(g);
   }
-  launch_gemm_group(probs.data(), (int)probs.size(), EPI_PLAIN, st);
+  launch_gemm_group(probs.data(), (int)probs.size(), EPI_PLAIN, st, h->mlp_split);
 }
 
 
@@ -652,6 +679,10 @@ void ani_destroy(ani_handle* h) {
     if (n.WT0c) (void)hipFree(n.WT0c);
     if (n.w_out) (void)hipFree(n.w_out);
     if (n.b_out) (void)hipFree(n.b_out);
+    for (unsigned short* p : n.W3) if (p) (void)hipFree(p);
+    for (unsigned short* p : n.WT3) if (p) (void)hipFree(p);
+    if (n.W0c3) (void)hipFree(n.W0c3);
+    if (n.WT0c3) (void)hipFree(n.WT0c3);
     for (double* p : n.W64) if (p) (void)hipFree(p);
     for (double* p : n.b64) if (p) (void)hipFree(p);
     for (double* p : n.WT64) if (p) (void)hipFree(p);
@@ -861,6 +892,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
     h->prune = value != 0;
     h->have_list = false;  // takes effect at the next rebuild (ago = 0), which the caller must issue
     h->active_mask = -1;
+    return ANI_OK;
+  }
+  if (strcmp(name, "mlp_split_bf16") == 0) {
+    h->mlp_split = value != 0;
     return ANI_OK;
   }
   if (strcmp(name, "full_radial_capacity") == 0) {

@@ -33,10 +33,20 @@ struct GemmArgs {
   int batch;
   float scale;             // LAST: 1/num_models
   float alpha, inv_alpha;  // CELU
+  // split-bf16 path: Bt as three bf16 planes (x = hi + mid + lo exactly), blocked [kb3][N][3][16] with kb3 = ceil(K/16)
+  // 16-k blocks per row (zero padded); sB3 = per-batch stride in bf16 elements.  NULL: only the fp32 path can run.
+  const unsigned short* Bt3;
+  long long sB3;
+  int kb3;
 };
 void launch_gemm(const GemmArgs& g, Epilogue epi, hipStream_t st);
-// one launch for several problems of the same epilogue (all species buckets of one layer)
-void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st);
+// one launch for several problems of the same epilogue (all species buckets of one layer).
+// split_bf16 = true: fp32 products evaluated as six bf16 MFMA products of the exact three-way splits of both operands
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation); false: v_mfma_f32_32x32x2_f32.
+void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st, bool split_bf16 = false);
+// dst[kb][N][3][16] bf16 planes of src[N][ld] (first K columns), kb = ceil(K/16); batch matrices src + i*s_src -> dst + i*N*kb*48
+void launch_split_bf16x3(const float* src, int batch, long long s_src, int N, int K, int ld, unsigned short* dst, hipStream_t st);
+inline size_t split_bf16x3_elems(int N, int K) { return (size_t)N * ((K + 15) / 16) * 48; }
 
 // x (double [ntotal*3]) + species -> float4 {x,y,z,bits of cmap[species]}
 struct SpeciesMap { int m[kMaxSpecies]; };

@@ -36,11 +36,131 @@ struct GroupArgs {
 };
 
 __device__ __forceinline__ float celu_f(float z, float alpha, float inv_alpha) {
-  return z > 0.f ? z : alpha * expm1f(z * inv_alpha);
+  // alpha * (exp(z/alpha) - 1) with the hardware exp2: for small |z| the subtraction loses relative, not absolute,
+  // accuracy -- the absolute error stays below 1e-7 * alpha, which is what the sums downstream see
+  return z > 0.f ? z : alpha * (__builtin_amdgcn_exp2f(z * inv_alpha * 1.4426950408889634f) - 1.f);
 }
 __device__ __forceinline__ float dcelu_from_h(float h, float inv_alpha) {
   // celu'(z) = 1 (z>0) or exp(z/alpha) = h/alpha + 1
   return h > 0.f ? 1.f : fmaf(h, inv_alpha, 1.f);
+}
+
+// Epilogues shared by the fp32-MFMA kernel and the split-bf16 kernel (same accumulator layout: col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).  `lds` is the workgroup's staging memory, free by now.
+template <int WM, int EPI, int NTW>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NTW], float* lds, int b, int n0, int row0, int t0,
+                                              int tcnt, int wm, int wn, int lr, int lh) {
+  constexpr int WN = 4 / WM;
+  constexpr int R = 32 * WM;
+  const int N = g.N;
+  float* __restrict__ C = g.C + (long long)b * g.sC;
+  const int mbase = row0 + 32 * wm + 4 * lh;
+  if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+      const int n = n0 + 32 * (t0 + nt) + lr;
+      if (nt < tcnt && n < N) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          C[(long long)m * g.ldc + n] = acc[nt][r];
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_CELU) {
+    const float* bias = g.bias + (long long)b * g.sBias;
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+      const int n = n0 + 32 * (t0 + nt) + lr;
+      if (nt < tcnt && n < N) {
+        const float bv = bias[n];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          C[(long long)m * g.ldc + n] = celu_f(acc[nt][r] + bv, g.alpha, g.inv_alpha);
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_BWD) {
+    const float* H = g.aux + (long long)b * g.sAux;
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+      const int n = n0 + 32 * (t0 + nt) + lr;
+      if (nt < tcnt && n < N) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          const float h = H[(long long)m * g.ldaux + n];
+          C[(long long)m * g.ldc + n] = acc[nt][r] * dcelu_from_h(h, g.inv_alpha);
+        }
+      }
+    }
+  } else {  // EPI_LAST: last hidden layer fused with the 1-wide output layer and the backward seed
+    const float* bias = g.bias + (long long)b * g.sBias;
+    const float* w = g.aux + (long long)b * g.sAux;
+    float esum[16], valid[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      esum[r] = 0.f;
+      const int m = mbase + (r & 3) + 8 * (r >> 2);
+      valid[r] = g.centre_of_row[m] >= 0 ? g.scale : 0.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+      const int n = n0 + 32 * (t0 + nt) + lr;
+      if (nt < tcnt && n < N) {
+        const float bv = bias[n], wv = w[n];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          const float h = celu_f(acc[nt][r] + bv, g.alpha, g.inv_alpha);
+          esum[r] = fmaf(h, wv, esum[r]);
+          // dE/dz = (1/M) * w_out * celu'(z)
+          C[(long long)m * g.ldc + n] = valid[r] * wv * dcelu_from_h(h, g.inv_alpha);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      float v = esum[r];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 1);
+      esum[r] = v;
+    }
+    const float bl = g.bias_last[b];
+    float* e_out = g.e_out + (long long)b * g.sE;
+    if constexpr (WN == 1) {
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = mbase + (r & 3) + 8 * (r >> 2);
+          e_out[m] = valid[r] * (esum[r] + bl);
+        }
+      }
+    } else {
+      // row sums are split over the WN wave columns: combine through LDS (staging buffers are free now)
+      __syncthreads();
+      float* red = lds;  // [WN][R]
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wn * R + 32 * wm + 4 * lh + (r & 3) + 8 * (r >> 2)] = esum[r];
+      }
+      __syncthreads();
+      if (wn == 0 && lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int rl = 32 * wm + 4 * lh + (r & 3) + 8 * (r >> 2);
+          float v = 0.f;
+#pragma unroll
+          for (int c = 0; c < WN; c++) v += red[c * R + rl];
+          e_out[row0 + rl] = valid[r] * (v + bl);
+        }
+      }
+    }
+  }
 }
 
 #ifndef ANI_GEMM_LB2
@@ -156,114 +276,221 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : (WM == 2 ? ANI_GEMM_LB2 : 3))) 
     }
   }
 
-  // ---- epilogue -------------------------------------------------------------------------------------
-  float* __restrict__ C = g.C + (long long)b * g.sC;
-  const int mbase = row0 + 32 * wm + 4 * lh;
-  if constexpr (EPI == EPI_PLAIN) {
+  gemm_epilogue<WM, EPI>(g, acc, lds, b, n0, row0, t0, tcnt, wm, wn, lr, lh);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 variant.  Every fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8 mantissa bits, same
+// exponent range): hi = x with the low 16 bits cleared, mid = (x - hi) likewise, lo = x - hi - mid.  A product a*b is
+// then the sum of nine bf16 x bf16 products, each exact in fp32; the six of them above 2^-24 relative size
+// (hh, hm, mh, hl, lh, mm) are evaluated with v_mfma_f32_32x32x16_bf16 and accumulated in fp32, the three dropped
+// ones (ml, lm, ll) sum to less than 2^-23 |a b| -- the size of one fp32 rounding.  On gfx950 a bf16 MFMA does 16x the
+// multiply-adds of an fp32 MFMA per cycle, so six of them cost 3/8 of the fp32-input instruction.
+// Weights are split once (launch_split_bf16x3); activations are split while they are staged into LDS.
+// LDS image of a staged row: [hi 16 k | mid 16 k | lo 16 k] bf16 = 96 B + 16 B pad (stride 112 B: conflict-free
+// ds_read_b128).  K is walked in slabs of 16 (one MFMA k-block).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned xb = __float_as_uint(x);
+  h = xb & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  l = __float_as_uint(r2);   // at most 8 significant bits left: its high half is exact
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo_elem, unsigned hi_elem) { return (lo_elem >> 16) | (hi_elem & 0xffff0000u); }
+
+template <int WM, int EPI, int KB>
+__global__ __launch_bounds__(256, (KB == 2 ? 2 : (WM == 4 ? 2 : 3))) void gemm_grouped_x3(GroupArgs G) {
+  constexpr int WN = 4 / WM;
+  constexpr int R = 32 * WM;
+  constexpr int NTW = 8 / WN;
+  constexpr int ROW = KB * 96 + 16;   // bytes per staged row: KB k-blocks of [hi|mid|lo] x 16 k, + pad (112 / 208: conflict-free)
+  __shared__ uint4 lds4[(R + 256) * ROW / 16];
+  unsigned char* As = reinterpret_cast<unsigned char*>(lds4);
+  unsigned char* Bs = As + R * ROW;
+
+  int pi = 0;
+  while (pi + 1 < G.nprob && (int)blockIdx.x >= G.tile_start[pi + 1]) pi++;
+  const GemmArgs& g = G.p[pi];
+  const int tiles_m = G.tiles_m[pi];
+  int local = blockIdx.x - G.tile_start[pi];
+  const int per_nb = tiles_m * g.batch;
+  const int nb = local / per_nb;
+  local -= nb * per_nb;
+  const int grp = local / (8 * g.batch);
+  const int rem = local - grp * (8 * g.batch);
+  const int gs = min(8, tiles_m - grp * 8);
+  const int b = rem / gs;
+  const int tile_m = grp * 8 + (rem - b * gs);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int n0 = nb * 256;
+  const int row0 = g.row0 + tile_m * R;
+  const int K = g.K, N = g.N;
+  const int ntiles = min(8, (N - n0 + 31) >> 5);
+  const int per = (ntiles + WN - 1) / WN;
+  const int t0 = wn * per;
+  const int tcnt = max(0, min(per, ntiles - t0));
+
+  const float* __restrict__ A = g.A + (long long)b * g.sA + (long long)row0 * g.lda;
+  // Bt planes are stored k-block major, [kb][N][hi|mid|lo][16]: the slab of one k-block is contiguous over the rows
+  const uint4* __restrict__ B3 = reinterpret_cast<const uint4*>(g.Bt3 + (long long)b * g.sB3);
+
+  f32x16 acc[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NTW; nt++) {
-      const int n = n0 + 32 * (t0 + nt) + lr;
-      if (nt < tcnt && n < N) {
+  for (int nt = 0; nt < NTW; nt++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          C[(long long)m * g.ldc + n] = acc[nt][r];
+    for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+
+  constexpr int PA = R >= 64 ? R / 64 : 1;   // A rows per thread
+  float4 pa[PA][KB];
+  uint4 pb[6 * KB];
+  const int ar = tid >> 2;          // A row (per 64-row group)
+  const int ak = (tid & 3) * 4;     // k offset inside a k-block
+  const int brows = min(32 * ntiles, N - n0);   // Bt rows staged by this workgroup, as 6 * brows 16-byte chunks
+
+  // A (activations) streams from HBM / Infinity Cache, Bt (weights) from L2: A is fetched two slabs ahead, Bt one
+  float4 pan[PA][KB];
+  auto gloadA = [&](int kb0, float4 (&dst)[PA][KB]) {
+#pragma unroll
+    for (int j = 0; j < KB; j++) {
+      const int kc = (kb0 + j) * 16 + ak;
+      const bool kin = kc < K;
+#pragma unroll
+      for (int i = 0; i < PA; i++) {
+        const int r = ar + 64 * i;
+        dst[i][j] = (kin && r < R) ? *reinterpret_cast<const float4*>(A + (long long)r * g.lda + kc) : make_float4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto gloadB = [&](int kb0) {
+#pragma unroll
+    for (int j = 0; j < KB; j++) {
+      const uint4* src = B3 + ((long long)(kb0 + j) * N + n0) * 6;
+      const bool bin = kb0 + j < g.kb3;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const int c = tid + 256 * i;   // consecutive lanes, consecutive 16-byte chunks
+        pb[6 * j + i] = (bin && c < 6 * brows) ? src[c] : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+
+  const int nkt = (g.kb3 + KB - 1) / KB;
+#ifdef ANI_GEMM_NO_KROT
+  const int rot = 0;
+#else
+  const int rot = (int)((blockIdx.x * 11u) % (unsigned)nkt);
+#endif
+  auto slab = [&](int kt) { int t = kt + rot; if (t >= nkt) t -= nkt; return t * KB; };
+  gloadA(slab(0), pa);
+  gloadB(slab(0));
+  if (nkt > 1) gloadA(slab(1), pan);
+  for (int kt = 0; kt < nkt; kt++) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PA; i++) {
+      const int r = ar + 64 * i;
+      if (r < R) {
+#pragma unroll
+        for (int j = 0; j < KB; j++) {
+          unsigned h[4], m[4], l[4];
+          split3(pa[i][j].x, h[0], m[0], l[0]); split3(pa[i][j].y, h[1], m[1], l[1]);
+          split3(pa[i][j].z, h[2], m[2], l[2]); split3(pa[i][j].w, h[3], m[3], l[3]);
+          unsigned char* dst = As + r * ROW + j * 96 + ak * 2;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+          *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
         }
       }
     }
-  } else if constexpr (EPI == EPI_CELU) {
-    const float* bias = g.bias + (long long)b * g.sBias;
 #pragma unroll
-    for (int nt = 0; nt < NTW; nt++) {
-      const int n = n0 + 32 * (t0 + nt) + lr;
-      if (nt < tcnt && n < N) {
-        const float bv = bias[n];
+    for (int j = 0; j < KB; j++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          C[(long long)m * g.ldc + n] = celu_f(acc[nt][r] + bv, g.alpha, g.inv_alpha);
+      for (int i = 0; i < 6; i++) {
+        const int c = tid + 256 * i;
+        const int r = c / 6, q = c - 6 * r;
+        if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + j * 96 + q * 16) = pb[6 * j + i];
+      }
+    __syncthreads();
+#ifndef ABLX_NO_GLOAD
+    if (kt + 1 < nkt) gloadB(slab(kt + 1));
+#pragma unroll
+    for (int i = 0; i < PA; i++)
+#pragma unroll
+      for (int j = 0; j < KB; j++) pa[i][j] = pan[i][j];
+    if (kt + 2 < nkt) gloadA(slab(kt + 2), pan);
+#endif
+#pragma unroll
+    for (int j = 0; j < KB; j++) {
+      const unsigned char* ap = As + (32 * wm + lr) * ROW + j * 96 + lh * 16;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
+      const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 64));
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++) {
+        if (nt < tcnt) {
+          const unsigned char* bp = Bs + (32 * (t0 + nt) + lr) * ROW + j * 96 + lh * 16;
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
+          const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 64));
+#ifdef ABLX_NO_MFMA
+          asm volatile("" ::"v"(ah), "v"(am), "v"(al), "v"(bh), "v"(bm), "v"(bl));
+          continue;
+#endif
+          // smallest terms first
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
         }
       }
     }
-  } else if constexpr (EPI == EPI_BWD) {
-    const float* H = g.aux + (long long)b * g.sAux;
-#pragma unroll
-    for (int nt = 0; nt < NTW; nt++) {
-      const int n = n0 + 32 * (t0 + nt) + lr;
-      if (nt < tcnt && n < N) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          const float h = H[(long long)m * g.ldaux + n];
-          C[(long long)m * g.ldc + n] = acc[nt][r] * dcelu_from_h(h, g.inv_alpha);
-        }
-      }
-    }
-  } else {  // EPI_LAST: last hidden layer fused with the 1-wide output layer and the backward seed
-    const float* bias = g.bias + (long long)b * g.sBias;
-    const float* w = g.aux + (long long)b * g.sAux;
-    float esum[16], valid[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      esum[r] = 0.f;
-      const int m = mbase + (r & 3) + 8 * (r >> 2);
-      valid[r] = g.centre_of_row[m] >= 0 ? g.scale : 0.f;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NTW; nt++) {
-      const int n = n0 + 32 * (t0 + nt) + lr;
-      if (nt < tcnt && n < N) {
-        const float bv = bias[n], wv = w[n];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          const float h = celu_f(acc[nt][r] + bv, g.alpha, g.inv_alpha);
-          esum[r] = fmaf(h, wv, esum[r]);
-          // dE/dz = (1/M) * w_out * celu'(z)
-          C[(long long)m * g.ldc + n] = valid[r] * wv * dcelu_from_h(h, g.inv_alpha);
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      float v = esum[r];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 8);
-      v += __shfl_xor(v, 4);
-      v += __shfl_xor(v, 2);
-      v += __shfl_xor(v, 1);
-      esum[r] = v;
-    }
-    const float bl = g.bias_last[b];
-    float* e_out = g.e_out + (long long)b * g.sE;
-    if constexpr (WN == 1) {
-      if (lr == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int m = mbase + (r & 3) + 8 * (r >> 2);
-          e_out[m] = valid[r] * (esum[r] + bl);
-        }
-      }
-    } else {
-      // row sums are split over the WN wave columns: combine through LDS (staging buffers are free now)
-      __syncthreads();
-      float* red = lds;  // [WN][R]
-      if (lr == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) red[wn * R + 32 * wm + 4 * lh + (r & 3) + 8 * (r >> 2)] = esum[r];
-      }
-      __syncthreads();
-      if (wn == 0 && lr == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int rl = 32 * wm + 4 * lh + (r & 3) + 8 * (r >> 2);
-          float v = 0.f;
-#pragma unroll
-          for (int c = 0; c < WN; c++) v += red[c * R + rl];
-          e_out[row0 + rl] = valid[r] * (v + bl);
-        }
-      }
-    }
+  }
+  __syncthreads();
+  gemm_epilogue<WM, EPI>(g, acc, reinterpret_cast<float*>(lds4), b, n0, row0, t0, tcnt, wm, wn, lr, lh);
+}
+
+// weights -> blocked bf16 planes
+__global__ void split_bf16x3_kernel(const float* __restrict__ src, long long s_src, int N, int K, int ld, int kb,
+                                    unsigned short* __restrict__ dst) {
+  const long long per = (long long)N * kb * 16;   // (row, k) slots per matrix
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int bi = blockIdx.y;
+  if (idx >= per) return;
+  const int n = (int)(idx / (kb * 16)), k = (int)(idx % (kb * 16));
+  const float x = k < K ? src[(long long)bi * s_src + (long long)n * ld + k] : 0.f;
+  unsigned h, m, l;
+  split3(x, h, m, l);
+  unsigned short* d = dst + (long long)bi * per * 3 + ((long long)(k / 16) * N + n) * 48 + (k % 16);
+  d[0] = (unsigned short)(h >> 16);
+  d[16] = (unsigned short)(m >> 16);
+  d[32] = (unsigned short)(l >> 16);
+}
+
+void launch_split_bf16x3(const float* src, int batch, long long s_src, int N, int K, int ld, unsigned short* dst, hipStream_t st) {
+  const int kb = (K + 15) / 16;
+  const long long per = (long long)N * kb * 16;
+  if (per <= 0 || batch <= 0) return;
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((per + 255) / 256), batch), dim3(256), 0, st, src, s_src, N, K, ld, kb, dst);
+}
+
+template <int WM, int KB>
+static void launch_wm_x3(const GroupArgs& G, Epilogue epi, int total, hipStream_t st) {
+  const dim3 grid(total), block(256);
+  switch (epi) {
+    case EPI_PLAIN: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_PLAIN, KB>), grid, block, 0, st, G); break;
+    case EPI_CELU: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_CELU, KB>), grid, block, 0, st, G); break;
+    case EPI_LAST: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_LAST, KB>), grid, block, 0, st, G); break;
+    case EPI_BWD: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_BWD, KB>), grid, block, 0, st, G); break;
   }
 }
 
@@ -296,7 +523,7 @@ static double makespan(const GemmArgs* probs, int nprob, int R, int ncu) {
   return total / (ncu * eff) + biggest;
 }
 
-void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st) {
+void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st, bool split_bf16) {
   static const int forced = [] { const char* e = getenv("ANI_GEMM_WM"); return e ? atoi(e) : 0; }();
   static const int ncu = [] {
     int dev = 0, n = 256;
@@ -328,9 +555,24 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
     }
     G.tile_start[G.nprob] = total;
     if (total == 0) continue;
-    if (WM == 4) launch_wm<4>(G, epi, total, st);
-    else if (WM == 2) launch_wm<2>(G, epi, total, st);
-    else launch_wm<1>(G, epi, total, st);
+    bool x3 = split_bf16;
+    for (int i = 0; i < G.nprob; i++) x3 = x3 && G.p[i].Bt3 != nullptr;
+    if (x3) {
+      static const int kbf = [] { const char* e = getenv("ANI_GEMM_KB"); return e ? atoi(e) : 1; }();
+      if (kbf == 2) {
+        if (WM == 4) launch_wm_x3<4, 2>(G, epi, total, st);
+        else if (WM == 2) launch_wm_x3<2, 2>(G, epi, total, st);
+        else launch_wm_x3<1, 2>(G, epi, total, st);
+      } else {
+        if (WM == 4) launch_wm_x3<4, 1>(G, epi, total, st);
+        else if (WM == 2) launch_wm_x3<2, 1>(G, epi, total, st);
+        else launch_wm_x3<1, 1>(G, epi, total, st);
+      }
+    } else {
+      if (WM == 4) launch_wm<4>(G, epi, total, st);
+      else if (WM == 2) launch_wm<2>(G, epi, total, st);
+      else launch_wm<1>(G, epi, total, st);
+    }
   }
 }
 
