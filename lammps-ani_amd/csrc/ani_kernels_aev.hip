@@ -508,16 +508,25 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
       const float sth = __builtin_amdgcn_sqrtf(fmaxf(1.f - cth * cth, 0.f));
       const float w = valid ? 2.f * L.afc[ia] * L.afc[ib] : 0.f;
       const float rho = 0.5f * (A.w + B.w);
+      // 16-byte stores (a lane's NZ / NA factors are contiguous): scalar stores at a 16- or 32-byte lane stride would
+      // be 4- and 8-way bank conflicts
+      float t1[NZ], t2[NA];
 #pragma unroll
       for (int z = 0; z < NZ; z++) {
         const float basez = fmaxf(0.5f * (1.f + cth * p.cosZ[z] + sth * p.sinZ[z]), 0.f);
-        L.pf1[lane * NZ + z] = w * fexp2(p.Zeta * flog2(basez));
+        t1[z] = w * fexp2(p.Zeta * flog2(basez));
       }
 #pragma unroll
       for (int s = 0; s < NA; s++) {
         const float dr = rho - p.ShfA[s];
-        L.pf2[lane * NA + s] = fexp2(cA * dr * dr);
+        t2[s] = fexp2(cA * dr * dr);
       }
+#pragma unroll
+      for (int z = 0; z < NZ; z += 4)
+        *reinterpret_cast<float4*>(L.pf1 + lane * NZ + z) = make_float4(t1[z], t1[z + 1], t1[z + 2], t1[z + 3]);
+#pragma unroll
+      for (int s = 0; s < NA; s += 4)
+        *reinterpret_cast<float4*>(L.pf2 + lane * NA + s) = make_float4(t2[s], t2[s + 1], t2[s + 2], t2[s + 3]);
       if ((lane % Q) == 0) L.pb[lane / Q] = outoff;
     }
     wave_sync();
@@ -529,7 +538,11 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
       const int slot = g * Q + lq;
       const float f2 = L.pf2[slot * NA + la];
 #pragma unroll
-      for (int z = 0; z < NZ; z++) acc[z] = fmaf(f2, L.pf1[slot * NZ + z], acc[z]);
+      for (int z = 0; z < NZ; z += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(L.pf1 + slot * NZ + z);
+        acc[z] = fmaf(f2, q.x, acc[z]); acc[z + 1] = fmaf(f2, q.y, acc[z + 1]);
+        acc[z + 2] = fmaf(f2, q.z, acc[z + 2]); acc[z + 3] = fmaf(f2, q.w, acc[z + 3]);
+      }
     }
     wave_sync();
   }

@@ -47,11 +47,10 @@ __device__ __forceinline__ float dcelu_from_h(float h, float inv_alpha) {
 
 // Epilogues shared by the fp32-MFMA kernel and the split-bf16 kernel (same accumulator layout: col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).  `lds` is the workgroup's staging memory, free by now.
-template <int WM, int EPI, int NTW>
+// R: rows of the workgroup tile, WN: wave columns, wm: index of this accumulator's 32-row strip inside the tile.
+template <int R, int WN, int EPI, int NTW>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NTW], float* lds, int b, int n0, int row0, int t0,
                                               int tcnt, int wm, int wn, int lr, int lh) {
-  constexpr int WN = 4 / WM;
-  constexpr int R = 32 * WM;
   const int N = g.N;
   float* __restrict__ C = g.C + (long long)b * g.sC;
   const int mbase = row0 + 32 * wm + 4 * lh;
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : (WM == 2 ? ANI_GEMM_LB2 : 3))) 
     }
   }
 
-  gemm_epilogue<WM, EPI>(g, acc, lds, b, n0, row0, t0, tcnt, wm, wn, lr, lh);
+  gemm_epilogue<32 * WM, 4 / WM, EPI>(g, acc, lds, b, n0, row0, t0, tcnt, wm, wn, lr, lh);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -302,10 +301,12 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 }
 __device__ __forceinline__ unsigned pack_hi16(unsigned lo_elem, unsigned hi_elem) { return (lo_elem >> 16) | (hi_elem & 0xffff0000u); }
 
-template <int WM, int EPI, int KB>
-__global__ __launch_bounds__(256, (KB == 2 ? 2 : (WM == 4 ? 2 : 3))) void gemm_grouped_x3(GroupArgs G) {
+// RT: 32-row strips per wave (register blocking in M).  The kernel is bound by LDS traffic, not by the MFMA pipe: with
+// RT = 2 every Bt fragment read from LDS feeds two row strips.
+template <int WM, int EPI, int KB, int RT>
+__global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))) void gemm_grouped_x3(GroupArgs G) {
   constexpr int WN = 4 / WM;
-  constexpr int R = 32 * WM;
+  constexpr int R = 32 * WM * RT;
   constexpr int NTW = 8 / WN;
   constexpr int ROW = KB * 96 + 16;   // bytes per staged row: KB k-blocks of [hi|mid|lo] x 16 k, + pad (112 / 208: conflict-free)
   __shared__ uint4 lds4[(R + 256) * ROW / 16];
@@ -342,11 +343,13 @@ __global__ __launch_bounds__(256, (KB == 2 ? 2 : (WM == 4 ? 2 : 3))) void gemm_g
   // Bt planes are stored k-block major, [kb][N][hi|mid|lo][16]: the slab of one k-block is contiguous over the rows
   const uint4* __restrict__ B3 = reinterpret_cast<const uint4*>(g.Bt3 + (long long)b * g.sB3);
 
-  f32x16 acc[NTW];
+  f32x16 acc[RT][NTW];
 #pragma unroll
-  for (int nt = 0; nt < NTW; nt++)
+  for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+    for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[rt][nt][r] = 0.f;
 
   constexpr int PA = R >= 64 ? R / 64 : 1;   // A rows per thread
   float4 pa[PA][KB];
@@ -429,10 +432,14 @@ __global__ __launch_bounds__(256, (KB == 2 ? 2 : (WM == 4 ? 2 : 3))) void gemm_g
 #endif
 #pragma unroll
     for (int j = 0; j < KB; j++) {
-      const unsigned char* ap = As + (32 * wm + lr) * ROW + j * 96 + lh * 16;
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
-      const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32));
-      const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 64));
+      bf16x8 ah[RT], am[RT], al[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        const unsigned char* ap = As + (32 * (wm * RT + rt) + lr) * ROW + j * 96 + lh * 16;
+        ah[rt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
+        am[rt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32));
+        al[rt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 64));
+      }
 #pragma unroll
       for (int nt = 0; nt < NTW; nt++) {
         if (nt < tcnt) {
@@ -441,22 +448,27 @@ __global__ __launch_bounds__(256, (KB == 2 ? 2 : (WM == 4 ? 2 : 3))) void gemm_g
           const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
           const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 64));
 #ifdef ABLX_NO_MFMA
-          asm volatile("" ::"v"(ah), "v"(am), "v"(al), "v"(bh), "v"(bm), "v"(bl));
+          asm volatile("" ::"v"(ah[0]), "v"(am[0]), "v"(al[0]), "v"(bh), "v"(bm), "v"(bl));
           continue;
 #endif
-          // smallest terms first
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) {
+            // smallest terms first
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[rt], bm, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[rt], bh, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bm, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][nt], 0, 0, 0);
+          }
         }
       }
     }
   }
   __syncthreads();
-  gemm_epilogue<WM, EPI>(g, acc, reinterpret_cast<float*>(lds4), b, n0, row0, t0, tcnt, wm, wn, lr, lh);
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+    gemm_epilogue<R, WN, EPI>(g, acc[rt], reinterpret_cast<float*>(lds4), b, n0, row0, t0, tcnt, wm * RT + rt, wn, lr, lh);
 }
 
 // weights -> blocked bf16 planes
@@ -483,14 +495,14 @@ void launch_split_bf16x3(const float* src, int batch, long long s_src, int N, in
   hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((per + 255) / 256), batch), dim3(256), 0, st, src, s_src, N, K, ld, kb, dst);
 }
 
-template <int WM, int KB>
+template <int WM, int KB, int RT>
 static void launch_wm_x3(const GroupArgs& G, Epilogue epi, int total, hipStream_t st) {
   const dim3 grid(total), block(256);
   switch (epi) {
-    case EPI_PLAIN: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_PLAIN, KB>), grid, block, 0, st, G); break;
-    case EPI_CELU: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_CELU, KB>), grid, block, 0, st, G); break;
-    case EPI_LAST: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_LAST, KB>), grid, block, 0, st, G); break;
-    case EPI_BWD: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_BWD, KB>), grid, block, 0, st, G); break;
+    case EPI_PLAIN: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_PLAIN, KB, RT>), grid, block, 0, st, G); break;
+    case EPI_CELU: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_CELU, KB, RT>), grid, block, 0, st, G); break;
+    case EPI_LAST: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_LAST, KB, RT>), grid, block, 0, st, G); break;
+    case EPI_BWD: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_BWD, KB, RT>), grid, block, 0, st, G); break;
   }
 }
 
@@ -559,14 +571,15 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
     for (int i = 0; i < G.nprob; i++) x3 = x3 && G.p[i].Bt3 != nullptr;
     if (x3) {
       static const int kbf = [] { const char* e = getenv("ANI_GEMM_KB"); return e ? atoi(e) : 1; }();
+      // 128-row tiles: 2x2 waves with two row strips each (RT = 2), not four waves stacked in M
       if (kbf == 2) {
-        if (WM == 4) launch_wm_x3<4, 2>(G, epi, total, st);
-        else if (WM == 2) launch_wm_x3<2, 2>(G, epi, total, st);
-        else launch_wm_x3<1, 2>(G, epi, total, st);
+        if (WM == 4) launch_wm_x3<2, 2, 2>(G, epi, total, st);
+        else if (WM == 2) launch_wm_x3<2, 2, 1>(G, epi, total, st);
+        else launch_wm_x3<1, 2, 1>(G, epi, total, st);
       } else {
-        if (WM == 4) launch_wm_x3<4, 1>(G, epi, total, st);
-        else if (WM == 2) launch_wm_x3<2, 1>(G, epi, total, st);
-        else launch_wm_x3<1, 1>(G, epi, total, st);
+        if (WM == 4) launch_wm_x3<2, 1, 2>(G, epi, total, st);
+        else if (WM == 2) launch_wm_x3<2, 1, 1>(G, epi, total, st);
+        else launch_wm_x3<1, 1, 1>(G, epi, total, st);
       }
     } else {
       if (WM == 4) launch_wm<4>(G, epi, total, st);
