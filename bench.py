@@ -238,9 +238,15 @@ def main():
         bf, bb = aev_bytes_per_step(aev_cols, nlocal_r, ntotal_r, npairs_r)
         mlp_roof = dict(bound="mfma", achieved=flops / (t_mlp * 1e-3) / 1e12 if t_mlp > 0 else None, peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", traffic=None,
-                        kernel="gemm_grouped (MLP forward + backward: 6 grouped launches per step, all species and members)",
-                        ms_per_step=t_mlp, flops_per_step=flops, flops_per_step_full_width_aev=flops_dense, aev_columns=aev_cols)
+                        kernel="gemm_grouped_x3 (MLP forward + backward: 6 grouped launches per step, all species and members)",
+                        ms_per_step=t_mlp, flops_per_step=flops, flops_per_step_full_width_aev=flops_dense, aev_columns=aev_cols,
+                        note="achieved = algorithmic fp32 flops / time, peak = the fp32-input MFMA peak.  The kernel evaluates each "
+                             "fp32 product as six v_mfma_f32_32x32x16_bf16 products of the exact hi/mid/lo bf16 splits of both "
+                             "operands (fp32 accumulate; same force error against the fp64 oracle as the fp32-input MFMA path, "
+                             "option mlp_split_bf16=0), so the MFMA pipe executes 6x these flops at the bf16 rate")
         mlp_roof["frac"] = mlp_roof["achieved"] / PEAK_F32_MFMA_TFLOPS if mlp_roof["achieved"] else None
+        # share of the step's MLP time the MFMA pipes are busy: 6 bf16 instructions of 32 cycles per 32x32x16 block
+        mlp_roof["mfma_pipe_busy_frac"] = (flops * 6 / (2 * 32 * 32 * 16) * 32 / (1024 * 2.4e9)) / (t_mlp * 1e-3) if t_mlp > 0 else None
         aev_roof = dict(bound="hbm", achieved=(bf + bb) / ((t_fwd + t_bwd) * 1e-3) / 1e9 if t_fwd + t_bwd > 0 else None,
                         peak=PEAK_HBM_GBS, unit="GB/s", traffic=None, kernel="aev_forward_fast + aev_backward_fast",
                         ms_per_step=t_fwd + t_bwd, ms_fwd=t_fwd, ms_bwd=t_bwd, bytes_per_step=bf + bb,
@@ -255,6 +261,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": (ns_day / PUBLISHED_NS_DAY[(args.atoms, args.models)]) if (world == 1 and (args.atoms, args.models) in PUBLISHED_NS_DAY) else None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 in/out and accumulation everywhere; MLP products via exact 3-way bf16 operand splits (6 MFMA terms)",
             "config": {"workload": f"water-{args.atoms} (rho=0.98 g/cm3), ANI-2x shaped seeded weights, {args.models} model(s), "
                                    f"pair_style ani 5.1 <model> hip {args.models} {args.aev} full single, skin 2.0, static positions, list reused (ago>0)",
                        "atoms": args.atoms, "models": args.models, "grid": list(wl.grid), "nlocal_rank0": inp.nlocal,
@@ -285,6 +292,16 @@ def main():
                              "max_abs_force": float(np.abs(fr).max()), "rms_force": float(np.sqrt((fr ** 2).mean())),
                              "energy_err_kcal_mol": float(abs(energy_local - ref["energy"])),
                              "tolerance_note": "north_star bar: 1e-4 eV/A = 2.3e-3 kcal/mol/A"}
+            # the same step with the MLP on fp32-input MFMA (v_mfma_f32_32x32x2_f32) instead of the split-bf16 products
+            ani.set_option("mlp_split_bf16", 0)
+            dt32, ph32 = wl.timed_run(max(args.steps // 5, 1), 2)
+            f32 = wl.d_f.view(-1, 3).cpu().numpy()
+            e32 = np.abs(f32[: inp.nlocal] - fr)
+            out["parity"]["fp32_input_mfma_path"] = {
+                "max_abs_force_err_kcal_mol_A": float(e32.max()), "rms_force_err": float(np.sqrt((e32 ** 2).mean())),
+                "max_abs_force_diff_to_split_path": float(np.abs(f32[: inp.nlocal] - f[: inp.nlocal]).max()),
+                "mlp_ms_per_step": ph32["mlp"] / max(ph32["calls"], 1)}
+            ani.set_option("mlp_split_bf16", 1)
     wl.close()
 
     if rank == 0 and world == 1 and not args.no_extra and (args.atoms, args.models) == (100002, 1):

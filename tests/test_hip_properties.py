@@ -121,3 +121,25 @@ def test_argument_errors(model_cache, hip):
     with pytest.raises(hip.AniError):
         hip.ANI(p, 0, use_num_models=5)                      # the file holds 2 members
     ani.close()
+
+
+def test_split_bf16_mlp_is_as_accurate_as_fp32_input_mfma(model_cache, hip):
+    """The default MLP path evaluates every fp32 product as six bf16 MFMA products of the exact hi/mid/lo splits of both
+    operands.  Against the fp64 oracle it must be as good as the fp32-input MFMA path (option mlp_split_bf16 = 0), and
+    the two must agree far inside the force tolerance; same for the full 8-member ensemble on a mixed-species box."""
+    from oracle import Oracle
+    for kind, nm, inp in (("ani2x", 1, hx.decompose(hx.water_box(1500, seed=5))),
+                          ("ani2x", 8, hx.decompose(hx.random_box(700, 7, 22.0, seed=9)))):
+        p = model_cache(kind, nm, 2024)
+        ref = Oracle(p).compute(inp)
+        ani = hip.ANI(p, 0)
+        a = ani.compute(inp, ago=0)
+        ani.set_option("mlp_split_bf16", 0)
+        b = ani.compute(inp, ago=0)
+        ea, eb = np.abs(a["force"] - ref["force"]).max(), np.abs(b["force"] - ref["force"]).max()
+        print(f"{kind} x{nm}: max|dF| split {ea:.2e}, fp32-input {eb:.2e}, between them {np.abs(a['force'] - b['force']).max():.2e}")
+        assert ea < F_TOL and eb < F_TOL
+        assert ea < 2.0 * eb + 1e-5
+        assert np.abs(a["force"] - b["force"]).max() < 0.25 * F_TOL
+        assert abs(a["energy"] - b["energy"]) < 1e-3 * max(1.0, inp.nlocal / 100.0)
+        ani.close()
