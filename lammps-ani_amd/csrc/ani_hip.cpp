@@ -101,7 +101,7 @@ struct ani_handle {
   DevBuf<int> nb_cell_id, nb_cell_count, nb_cell_start, nb_cursor, nb_order;  // device-side list build (row f1)
   DevBuf<double> nb_xs;
   std::vector<std::vector<double*>> Hbuf64;
-  std::vector<std::vector<float*>> Hbuf, Gbuf;  // [S][k] pointers into act
+  std::vector<std::vector<float*>> Hbuf, Gbuf;  // [S][k] pointers into act: stored activations H_k; raw (unmasked) dE/dh_k
   // host staging for the host-pointer entry points
   std::vector<int> h_species32;
   std::vector<int> h_half_num, h_half_j;
@@ -358,20 +358,27 @@ int rebuild(ani_handle* h, hipStream_t st) {
   HIP_TRY(h, hipMemsetAsync(h->aev.p, 0, (size_t)h->nrows * stride * sizeof(float), st));  // padding rows stay zero
   HIP_TRY(h, h->e_rows.reserve((size_t)m.M * std::max(h->nrows, 1)));
 
-  // activation arena: per species, H_k (k = 1..L-2, reused in place as G_k) and G_{L-1}
+  // activation arena: per species, H_k (k = 1..L-1; H_{L-1} is overwritten by dE/dz_{L-1}) and the raw gradients
+  // dE/dh_k (k = 1..L-2), whose celu' factor is applied by the product that consumes them
   size_t need = 0;
   for (int s = 0; s < m.S; s++) {
     const size_t rows = round_up(h->count[s], kRowTile);
     for (int k = 1; k < m.L; k++) need += rows * (size_t)m.M * h->nets[s].w[k];
+    for (int k = 1; k < m.L - 1; k++) need += rows * (size_t)m.M * h->nets[s].w[k];
   }
   HIP_TRY(h, h->act.reserve(std::max<size_t>(need, 1)));
   HIP_TRY(h, hipMemsetAsync(h->act.p, 0, need * sizeof(float), st));  // zero K-padding columns
   h->Hbuf.assign(m.S, std::vector<float*>(m.L, nullptr));
+  h->Gbuf.assign(m.S, std::vector<float*>(m.L, nullptr));
   size_t off = 0;
   for (int s = 0; s < m.S; s++) {
     const size_t rows = round_up(h->count[s], kRowTile);
     for (int k = 1; k < m.L; k++) {
       h->Hbuf[s][k] = h->act.p + off;
+      off += rows * (size_t)m.M * h->nets[s].w[k];
+    }
+    for (int k = 1; k < m.L - 1; k++) {
+      h->Gbuf[s][k] = h->act.p + off;
       off += rows * (size_t)m.M * h->nets[s].w[k];
     }
   }
@@ -431,7 +438,10 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
     }
     launch_gemm_group(probs.data(), (int)probs.size(), k == L - 2 ? EPI_LAST : EPI_CELU, st, h->mlp_split);
   }
-  // backward: G_{k-1} = (G_k W[k-1]) * celu'(z_{k-1}), in place over H_{k-1}
+  // backward: dE/dh_{k-1} = G_k W[k-1] with G_k = dE/dh_k * celu'(z_k).  The celu' factor of a layer is applied when
+  // its raw gradient is staged as the A operand of the next product (Amask = the stored activation H_k), not in the
+  // epilogue of the product that made it: the H loads then ride the prefetch pipeline instead of stalling the epilogue.
+  // G_{L-1} comes fully formed out of the fused last forward layer.
   for (int k = L - 1; k >= 2; k--) {
     probs.clear();
     for (int s = 0; s < m.S; s++) {
@@ -439,15 +449,16 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
       const SpeciesNet& n = h->nets[s];
       const std::vector<int>& d = m.dims[s];
       GemmArgs g = base_args(s);
-      g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k]; g.K = n.w[k];
+      g.A = (k == L - 1) ? h->Hbuf[s][k] : h->Gbuf[s][k];
+      g.Amask = (k == L - 1) ? nullptr : h->Hbuf[s][k];
+      g.lda = M * n.w[k]; g.sA = n.w[k]; g.K = n.w[k];
       g.Bt = n.WT[k - 1]; g.ldb = n.w[k]; g.sB = (long long)d[k - 1] * n.w[k];
       g.N = d[k - 1];
       g.Bt3 = n.WT3[k - 1]; g.kb3 = (g.K + 15) / 16; g.sB3 = (long long)split_bf16x3_elems(g.N, g.K);
-      g.aux = h->Hbuf[s][k - 1]; g.ldaux = M * n.w[k - 1]; g.sAux = n.w[k - 1];
-      g.C = h->Hbuf[s][k - 1]; g.ldc = M * n.w[k - 1]; g.sC = n.w[k - 1];
+      g.C = h->Gbuf[s][k - 1]; g.ldc = M * n.w[k - 1]; g.sC = n.w[k - 1];
       probs.push_back(g);
     }
-    launch_gemm_group(probs.data(), (int)probs.size(), EPI_BWD, st, h->mlp_split);
+    launch_gemm_group(probs.data(), (int)probs.size(), EPI_PLAIN, st, h->mlp_split);
   }
   // dE/dAEV = sum over members of G_1 W[0]  (members concatenated along K)
   probs.clear();
@@ -456,7 +467,7 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
     const SpeciesNet& n = h->nets[s];
     GemmArgs g = base_args(s);
     g.batch = 1;
-    g.A = h->Hbuf[s][1]; g.lda = M * n.w[1]; g.K = M * n.w[1];
+    g.A = h->Gbuf[s][1]; g.Amask = h->Hbuf[s][1]; g.lda = M * n.w[1]; g.K = M * n.w[1];
     g.Bt = n.WT0c ? n.WT0c : n.WT[0]; g.ldb = M * n.w[1];
     g.N = h->ap_run.aev_len;
     g.Bt3 = n.WT0c ? n.WT0c3 : n.WT3[0]; g.kb3 = (g.K + 15) / 16; g.sB3 = 0;

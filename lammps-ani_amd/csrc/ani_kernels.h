@@ -18,6 +18,8 @@ enum Epilogue { EPI_PLAIN = 0, EPI_CELU = 1, EPI_LAST = 2, EPI_BWD = 3 };
 // C[rows][N] = epi( A[rows][K] * Bt[N][K]^T ), fp32 MFMA.  Batched over blockIdx.y (ensemble members).
 struct GemmArgs {
   const float* A;
+  const float* Amask;      // optional, same shape/strides as A: the stored activation H of the layer A was differentiated
+                           // through; the kernel then multiplies A by celu'(z) = (H > 0 ? 1 : H/alpha + 1) while staging it
   const float* Bt;
   float* C;
   const float* bias;       // [N] per batch            (CELU, LAST)

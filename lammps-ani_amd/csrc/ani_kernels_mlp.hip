@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : (WM == 2 ? ANI_GEMM_LB2 : 3))) 
     for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
 
   constexpr int PA = R / 32;  // float4 per thread for the A slab
-  float4 pa[PA], pb[8];
+  float4 pa[PA], pb[8], pm[PA];
+  const float* __restrict__ Am = g.Amask ? g.Amask + (long long)b * g.sA + (long long)row0 * g.lda : nullptr;
   const int cr = tid >> 3;         // staged row handled by this thread (per 32-row group)
   const int ck = (tid & 7) * 4;    // k offset inside the slab
   const int brows = 32 * ntiles;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : (WM == 2 ? ANI_GEMM_LB2 : 3))) 
     for (int i = 0; i < PA; i++) {
       const int r = cr + 32 * i;
       pa[i] = kin ? *reinterpret_cast<const float4*>(A + (long long)r * g.lda + kc) : make_float4(0, 0, 0, 0);
+      if (Am) pm[i] = kin ? *reinterpret_cast<const float4*>(Am + (long long)r * g.lda + kc) : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -247,7 +249,13 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : (WM == 2 ? ANI_GEMM_LB2 : 3))) 
   for (int kt = 0; kt < nkt; kt++) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < PA; i++) *reinterpret_cast<float4*>(As + (cr + 32 * i) * LDS_LD + ck) = pa[i];
+    for (int i = 0; i < PA; i++) {
+      if (Am) {
+        pa[i].x *= dcelu_from_h(pm[i].x, g.inv_alpha); pa[i].y *= dcelu_from_h(pm[i].y, g.inv_alpha);
+        pa[i].z *= dcelu_from_h(pm[i].z, g.inv_alpha); pa[i].w *= dcelu_from_h(pm[i].w, g.inv_alpha);
+      }
+      *reinterpret_cast<float4*>(As + (cr + 32 * i) * LDS_LD + ck) = pa[i];
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++)
       if (cr + 32 * i < brows) *reinterpret_cast<float4*>(Bs + (cr + 32 * i) * LDS_LD + ck) = pb[i];
@@ -359,8 +367,9 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
   const int brows = min(32 * ntiles, N - n0);   // Bt rows staged by this workgroup, as 6 * brows 16-byte chunks
 
   // A (activations) streams from HBM / Infinity Cache, Bt (weights) from L2: A is fetched two slabs ahead, Bt one
-  float4 pan[PA][KB];
-  auto gloadA = [&](int kb0, float4 (&dst)[PA][KB]) {
+  float4 pan[PA][KB], pm[PA][KB], pmn[PA][KB];
+  const float* __restrict__ Am = g.Amask ? g.Amask + (long long)b * g.sA + (long long)row0 * g.lda : nullptr;
+  auto gloadA = [&](int kb0, float4 (&dst)[PA][KB], float4 (&dstm)[PA][KB]) {
 #pragma unroll
     for (int j = 0; j < KB; j++) {
       const int kc = (kb0 + j) * 16 + ak;
@@ -368,7 +377,9 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
 #pragma unroll
       for (int i = 0; i < PA; i++) {
         const int r = ar + 64 * i;
-        dst[i][j] = (kin && r < R) ? *reinterpret_cast<const float4*>(A + (long long)r * g.lda + kc) : make_float4(0, 0, 0, 0);
+        const bool in = kin && r < R;
+        dst[i][j] = in ? *reinterpret_cast<const float4*>(A + (long long)r * g.lda + kc) : make_float4(0, 0, 0, 0);
+        if (Am) dstm[i][j] = in ? *reinterpret_cast<const float4*>(Am + (long long)r * g.lda + kc) : make_float4(0, 0, 0, 0);
       }
     }
   };
@@ -392,9 +403,9 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
   const int rot = (int)((blockIdx.x * 11u) % (unsigned)nkt);
 #endif
   auto slab = [&](int kt) { int t = kt + rot; if (t >= nkt) t -= nkt; return t * KB; };
-  gloadA(slab(0), pa);
+  gloadA(slab(0), pa, pm);
   gloadB(slab(0));
-  if (nkt > 1) gloadA(slab(1), pan);
+  if (nkt > 1) gloadA(slab(1), pan, pmn);
   for (int kt = 0; kt < nkt; kt++) {
     __syncthreads();
 #pragma unroll
@@ -403,9 +414,14 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
       if (r < R) {
 #pragma unroll
         for (int j = 0; j < KB; j++) {
+          float4 av = pa[i][j];
+          if (Am) {
+            av.x *= dcelu_from_h(pm[i][j].x, g.inv_alpha); av.y *= dcelu_from_h(pm[i][j].y, g.inv_alpha);
+            av.z *= dcelu_from_h(pm[i][j].z, g.inv_alpha); av.w *= dcelu_from_h(pm[i][j].w, g.inv_alpha);
+          }
           unsigned h[4], m[4], l[4];
-          split3(pa[i][j].x, h[0], m[0], l[0]); split3(pa[i][j].y, h[1], m[1], l[1]);
-          split3(pa[i][j].z, h[2], m[2], l[2]); split3(pa[i][j].w, h[3], m[3], l[3]);
+          split3(av.x, h[0], m[0], l[0]); split3(av.y, h[1], m[1], l[1]);
+          split3(av.z, h[2], m[2], l[2]); split3(av.w, h[3], m[3], l[3]);
           unsigned char* dst = As + r * ROW + j * 96 + ak * 2;
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
           *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
@@ -427,8 +443,8 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
 #pragma unroll
     for (int i = 0; i < PA; i++)
 #pragma unroll
-      for (int j = 0; j < KB; j++) pa[i][j] = pan[i][j];
-    if (kt + 2 < nkt) gloadA(slab(kt + 2), pan);
+      for (int j = 0; j < KB; j++) { pa[i][j] = pan[i][j]; pm[i][j] = pmn[i][j]; }
+    if (kt + 2 < nkt) gloadA(slab(kt + 2), pan, pmn);
 #endif
 #pragma unroll
     for (int j = 0; j < KB; j++) {
