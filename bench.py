@@ -250,9 +250,26 @@ def main():
         aev_roof = dict(bound="hbm", achieved=(bf + bb) / ((t_fwd + t_bwd) * 1e-3) / 1e9 if t_fwd + t_bwd > 0 else None,
                         peak=PEAK_HBM_GBS, unit="GB/s", traffic=None, kernel="aev_forward_fast + aev_backward_fast",
                         ms_per_step=t_fwd + t_bwd, ms_fwd=t_fwd, ms_bwd=t_bwd, bytes_per_step=bf + bb,
-                        note="issue-bound, not HBM-bound: ~3300 VALU wave-instructions per centre (DESIGN.md 3.1); "
-                             "measured FETCH/WRITE_SIZE in profiles/r01_pmc_notes.md")
+                        note="issue-bound, not HBM-bound: ~3300 VALU wave-instructions per centre, forward + backward (DESIGN.md 3.1); "
+                             "counters in profiles/r01_e_pmc_summary.json")
         aev_roof["frac"] = aev_roof["achieved"] / PEAK_HBM_GBS if aev_roof["achieved"] else None
+        # HBM traffic per launch from the PMC passes of the same command (tools/profile_round.sh; FETCH_SIZE and
+        # WRITE_SIZE in separate runs, KB; FETCH_SIZE doubled: gfx950 counts half of a wide read, MI355X_MICROARCH.md)
+        pmc_file = os.path.join(ROOT, "profiles", "r01_e_pmc_summary.json")
+        if world == 1 and (args.atoms, args.models) == (100002, 1) and not args.dense_aev and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+
+            def hbm_bytes(prefix):
+                tot = 0.0
+                for name, c in pmc.items():
+                    if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                        per_step = c["FETCH_SIZE"]["launches"] / max(pmc["ani::pack_kernel"]["FETCH_SIZE"]["launches"], 1)
+                        tot += (2.0 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024.0 * per_step
+                return tot
+            aev_roof["traffic"] = hbm_bytes("ani::aev_")
+            aev_roof["traffic_note"] = "bytes per step, forward + backward launch; profiles/r01_e_pmc_summary.json"
+            mlp_roof["traffic"] = hbm_bytes("ani::gemm_grouped")
+            mlp_roof["traffic_note"] = "bytes per step over the 6 launches; profiles/r01_e_pmc_summary.json"
         dominant, other = (mlp_roof, aev_roof) if t_mlp >= t_fwd + t_bwd else (aev_roof, mlp_roof)
 
         out = {
