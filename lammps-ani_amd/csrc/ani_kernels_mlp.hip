@@ -565,6 +565,9 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
       const double m32 = makespan(probs + base, np, 32, ncu), m64 = makespan(probs + base, np, 64, ncu),
                    m128 = makespan(probs + base, np, 128, ncu);
       WM = (m32 < m64 && m32 < m128) ? 1 : (m64 < m128 ? 2 : 4);
+      // the split-bf16 kernel is bound by its staging skeleton, not by MFMA time: 64-row tiles (3 workgroups per CU) won
+      // at every size measured (12.5k .. 100k atoms per GPU), the makespan model above was fitted to the fp32-input kernel
+      if (split_bf16) WM = 2;
     }
     const int R = 32 * WM;
     GroupArgs G;
