@@ -101,14 +101,20 @@ class Workload:
         for w in range(warmup):
             self.step(w + 1)
         self.sync_all()
-        self.ani.phase_timing(True)
+        # the per-phase HIP events (5 records per step, each a ~5 us bubble on the stream) are sampled on every 4th
+        # step only: at small per-GPU sizes they would otherwise cost several percent of the step being measured
+        self.ani.phase_timing(1)   # fresh accumulation ...
+        self.ani.phase_timing(0)   # ... recording paused
         t0 = time.perf_counter()
         for k in range(nsteps):
+            if k % 4 == 0:
+                self.ani.phase_timing(2)
             self.step(warmup + 1 + k)
+            if k % 4 == 0:
+                self.ani.phase_timing(0)
         self.sync_all()
         dt = time.perf_counter() - t0
         ph = self.ani.phase_times()
-        self.ani.phase_timing(False)
         return dt, ph
 
     def close(self):

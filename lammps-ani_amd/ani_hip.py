@@ -180,7 +180,8 @@ class ANI:
     def set_option(self, name: str, value: int):
         self._check(self._lib.ani_set_option(self._h, name.encode(), int(value)))
 
-    def phase_timing(self, enable: bool):
+    def phase_timing(self, enable):
+        """1/True: fresh accumulation; 0/False: stop recording; 2: resume without clearing."""
         self._check(self._lib.ani_phase_timing(self._h, int(enable)))
 
     def phase_times(self):

@@ -928,9 +928,11 @@ int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t by
 int ani_phase_timing(ani_handle* h, int enable) {
   if (!h) return ANI_ERR_ARG;
   h->timing = enable != 0;
-  for (double& v : h->phase_ms) v = 0;
-  h->phase_calls = 0;
-  h->evt_used = 0;
+  if (enable == 1) {  // fresh accumulation; 0 (stop) and 2 (resume) keep what has been recorded
+    for (double& v : h->phase_ms) v = 0;
+    h->phase_calls = 0;
+    h->evt_used = 0;
+  }
   return ANI_OK;
 }
 
