@@ -143,3 +143,37 @@ def test_split_bf16_mlp_is_as_accurate_as_fp32_input_mfma(model_cache, hip):
         assert np.abs(a["force"] - b["force"]).max() < 0.25 * F_TOL
         assert abs(a["energy"] - b["energy"]) < 1e-3 * max(1.0, inp.nlocal / 100.0)
         ani.close()
+
+
+def test_screened_radial_capacity_overflow_is_loud_and_option_restores_it(model_cache, hip):
+    """With the radial screen on, LDS is reserved for 3/4 of the longest neighbour list.  A cluster in vacuum whose
+    whole 7.1 A list sits inside 5.1 A (the one geometry where that estimate is wrong) must raise the capacity error,
+    and option full_radial_capacity must then give the oracle's answer."""
+    from oracle import Oracle
+    p = model_cache("ani2x", 1, 2024)
+    rng = np.random.default_rng(11)
+    pts = []
+    while len(pts) < 240:                                   # 240 atoms in a 5 A ball: every atom sees >128 others < 5.1 A
+        q = rng.uniform(-2.5, 2.5, 3)
+        if q @ q < 2.5 ** 2 and all(np.sum((q - r) ** 2) > 0.55 ** 2 for r in pts):
+            pts.append(q)
+    s = hx.System(np.array(pts), np.full(240, 1, np.int32), np.full(3, -30.0), np.full(3, 30.0), (False,) * 3)
+    inp = hx.decompose(s)
+    assert inp.numneigh.max() > 171                         # 3/4 of it rounds to 192 slots at most
+    ani = hip.ANI(p, 0)
+    with pytest.raises(hip.AniError, match="capacity"):
+        ani.compute(inp, ago=0)
+    ani.close()
+    # the angular capacity (96 within 3.5 A) also overflows for this blob, so check the option on a sparser ball
+    shell = np.array(pts) * 3.0                              # 7.5 A radius: <= ~80 atoms within 5.1 A, lists of ~200
+    s2 = hx.System(shell, np.full(240, 1, np.int32), np.full(3, -40.0), np.full(3, 40.0), (False,) * 3)
+    inp2 = hx.decompose(s2)
+    ani = hip.ANI(p, 0)
+    ani.set_option("full_radial_capacity", 1)
+    got = ani.compute(inp2, ago=0)
+    ref = Oracle(p).compute(inp2)
+    assert np.abs(got["force"] - ref["force"]).max() < F_TOL
+    ani.set_option("full_radial_capacity", 0)
+    got2 = ani.compute(inp2, ago=0)
+    assert np.abs(got2["force"] - got["force"]).max() < 1e-4
+    ani.close()
