@@ -484,7 +484,7 @@ int run_step64(ani_handle* h, const double* d_x, int eflag_atom, int vflag, doub
   const HostModel& m = h->model;
   const int L = m.L, M = m.M;
   HIP_TRY(h, h->fbuf64.reserve((size_t)std::max(h->ntotal, 1) * 3));
-  HIP_TRY(h, h->virial_acc.reserve(9));
+  HIP_TRY(h, h->virial_acc.reserve(9 * kVirialSlots));
   HIP_TRY(h, h->err_flag.reserve(1, true));
   HIP_TRY(h, hipMemsetAsync(h->fbuf64.p, 0, sizeof(double) * 3 * (size_t)h->ntotal, st));
   HIP_TRY(h, hipMemsetAsync(h->virial_acc.p, 0, sizeof(double) * 9, st));
@@ -566,7 +566,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   HIP_TRY(h, h->xyzs.reserve(h->ntotal));
   HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 4));  // one float4 per atom
   HIP_TRY(h, h->partial.reserve(256));
-  HIP_TRY(h, h->virial_acc.reserve(9));
+  HIP_TRY(h, h->virial_acc.reserve(9 * kVirialSlots));
   HIP_TRY(h, h->err_flag.reserve(1, true));
   if (h->timing) {
     if (h->evt_used + 5 > h->evt_pool.size()) {

@@ -12,6 +12,7 @@ constexpr int kRowTile = 128;   // AEV rows per GEMM block; species buckets are 
 constexpr int kMaxRad = 256;    // per-centre capacity of the radial neighbour list held in LDS
 constexpr int kMaxAng = 96;     // per-centre capacity of the angular neighbour list held in LDS
 constexpr int kBucketInfoInts = 2 * kMaxSpecies + 4;
+constexpr int kVirialSlots = 1024;  // rows of 9 doubles the waves of the AEV backward spread their virial sums over
 
 enum Epilogue { EPI_PLAIN = 0, EPI_CELU = 1, EPI_LAST = 2, EPI_BWD = 3 };
 
@@ -52,7 +53,7 @@ inline size_t split_bf16x3_elems(int N, int K) { return (size_t)N * ((K + 15) / 
 
 // x (double [ntotal*3]) + species -> float4 {x,y,z,bits of cmap[species]}
 struct SpeciesMap { int m[kMaxSpecies]; };
-// also clears this step's accumulators: fbuf[4*ntotal] and virial_acc[9] (no separate memsets)
+// also clears this step's accumulators: fbuf[4*ntotal] and virial_acc[kVirialSlots*9] (no separate memsets)
 void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
                  double* virial_acc, hipStream_t st);
 
@@ -79,7 +80,8 @@ struct AevArgs {
   float* aev;        // [nrows][aev_stride]
   const float* gaev; // backward only
   float* fbuf;       // backward: [ntotal*4] float accumulators {fx,fy,fz,-} (Hartree/Angstrom), atomically added
-  double* virial;    // backward: [9] (Hartree), atomically added; may be NULL
+  double* virial;    // backward: [kVirialSlots][9] (Hartree) partial sums, atomically added (fast path: slot = wave id
+                     // mod kVirialSlots; other kernels use slot 0); may be NULL
   int* err_flag;     // set to 1 on LDS capacity overflow
 };
 // max_numneigh (known at rebuild) sizes the per-centre LDS neighbour lists of the fast path
@@ -121,7 +123,7 @@ struct FinishArgs {
   double sae[kMaxSpecies];
   const float* fbuf;     // [ntotal*4] {fx,fy,fz,-}
   int ntotal;
-  const double* virial_acc;  // [9] Hartree (unsymmetrised), or NULL
+  const double* virial_acc;  // [kVirialSlots][9] Hartree (unsymmetrised partial sums), or NULL
   double* f_out;         // [ntotal*3] kcal/mol/A
   int f_accumulate;      // 1: +=, 0: overwrite
   double* ev_out;        // [10]

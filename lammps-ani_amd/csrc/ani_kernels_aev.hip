@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, Aev
 
 template <int NA, int NZ, int NCH, int GR>
 __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row,
-                                                const Prefetched<NCH>& pf, const float4 (&grow)[GR], int lane) {
+                                                const Prefetched<NCH>& pf, const float4 (&grow)[GR], int lane, float (&wv)[9]) {
   constexpr int NR = 16;
   const int4 info = pf.info;
 #pragma unroll
@@ -743,16 +743,18 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
 
   // ---- scatter: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d ----
   float fx = 0.f, fy = 0.f, fz = 0.f;
-  float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int q = lane; q < nrad; q += 64) {
     const float gx = L.gd[3 * q], gy = L.gd[3 * q + 1], gz = L.gd[3 * q + 2];
     fx += gx; fy += gy; fz += gz;
-    if (a.virial) {
-      const float dx = L.rdx[q], dy = L.rdy[q], dz = L.rdz[q];
-      v[0] += gx * dx; v[1] += gx * dy; v[2] += gx * dz;
-      v[3] += gy * dx; v[4] += gy * dy; v[5] += gy * dz;
-      v[6] += gz * dx; v[7] += gz * dy; v[8] += gz * dz;
-    }
+    // virial: per-lane partial sums kept across all the centres of this wave; the nine totals are reduced over the
+    // lanes and added to the global accumulator ONCE per wave at the end of the kernel (nine double atomics per centre
+    // on nine addresses serialise at the memory side: 10 ms per step at 100 000 centres).  Accumulated whether or not
+    // the caller wants the virial: 12 instructions per centre, and a test here makes the compiler clone the whole
+    // centre loop into a slower second version.
+    const float dx = L.rdx[q], dy = L.rdy[q], dz = L.rdz[q];
+    wv[0] += gx * dx; wv[1] += gx * dy; wv[2] += gx * dz;
+    wv[3] += gy * dx; wv[4] += gy * dy; wv[5] += gy * dz;
+    wv[6] += gz * dx; wv[7] += gz * dy; wv[8] += gz * dz;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -771,15 +773,6 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   }
 #endif
   if (lane < 3) atomicAdd(&a.fbuf[4 * i + lane], lane == 0 ? fx : (lane == 1 ? fy : fz));
-  if (a.virial) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-      float sv = v[k];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off);
-      if (lane == 0) atomicAdd(&a.virial[k], -(double)sv);
-    }
-  }
   wave_sync();  // the LDS slice is reused by this wave's next centre
 }
 
@@ -792,6 +785,7 @@ __global__ __launch_bounds__(64 * kWavesB, 3) void aev_backward_fast(AevParams p
   // 1024), issued BEFORE this iteration's prefetch loads so that the wait for it (vmcnt counts in order) leaves the
   // younger prefetches in flight
   float4 grow[GR];
+  float wv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this lane's share of the wave's virial
   const int n4 = p.aev_stride >> 2;
   ANI_PERSISTENT_LOOP(kWavesB, NCH,
                       {
@@ -799,7 +793,16 @@ __global__ __launch_bounds__(64 * kWavesB, 3) void aev_backward_fast(AevParams p
                         _Pragma("unroll") for (int c = 0; c < GR; c++) grow[c] =
                             (cur.info.x >= 0 && lane + 64 * c < n4) ? g4[lane + 64 * c] : make_float4(0, 0, 0, 0);
                       },
-                      (backward_centre<NA, NZ, NCH, GR>(p, a, cap, L, row, cur, grow, lane)))
+                      (backward_centre<NA, NZ, NCH, GR>(p, a, cap, L, row, cur, grow, lane, wv)))
+  if (a.virial) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      double sv = (double)wv[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off);
+      if (lane == 0) atomicAdd(&a.virial[9 * ((blockIdx.x * kWavesB + wave) & (kVirialSlots - 1)) + k], -sv);
+    }
+  }
 }
 
 // =====================================================================================================

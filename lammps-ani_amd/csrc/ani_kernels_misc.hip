@@ -9,7 +9,7 @@ namespace ani {
 __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int ntotal, SpeciesMap cmap,
                             float4* __restrict__ out, float* __restrict__ fbuf, double* __restrict__ virial_acc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 9) virial_acc[i] = 0.0;
+  if (i < 9 * kVirialSlots) virial_acc[i] = 0.0;
   if (i >= ntotal) return;
   // coordinates.to(dtype): src/ani_csrc/ani.cpp:206-207.  The species stored next to the position is the index the
   // AEV kernels use (compact index among the species present in this system, see ani_hip.cpp:specialize).
@@ -21,7 +21,8 @@ __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict_
 
 void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
                  double* virial_acc, hipStream_t st) {
-  hipLaunchKernelGGL(pack_kernel, dim3(ntotal > 0 ? (ntotal + 255) / 256 : 1), dim3(256), 0, st, d_x, d_species, ntotal, cmap,
+  const int nthr = ntotal > 9 * kVirialSlots ? ntotal : 9 * kVirialSlots;
+  hipLaunchKernelGGL(pack_kernel, dim3((nthr + 255) / 256), dim3(256), 0, st, d_x, d_species, ntotal, cmap,
                      xyzs, fbuf, virial_acc);
 }
 
@@ -153,11 +154,28 @@ __global__ __launch_bounds__(256) void finish_final_kernel(FinishArgs a) {
     __syncthreads();
   }
   if (threadIdx.x == 0) a.ev_out[0] = (a.err_flag && *a.err_flag) ? __longlong_as_double(0x7ff8000000000000LL) : red[0] * 627.5094738898777;
+  // virial: sum the partial rows, then (virial.t() + virial)/2 : models/lammps_ani.py:200
+  if (!a.virial_acc) {   // kernel-argument uniform
+    if (threadIdx.x < 9) a.ev_out[1 + threadIdx.x] = 0.0;
+    return;
+  }
+  __shared__ double vsum[9];
+  __syncthreads();
+  for (int c = 0; c < 9; c++) {
+    double t = 0.0;
+    for (int sl = threadIdx.x; sl < kVirialSlots; sl += blockDim.x) t += a.virial_acc[9 * sl + c];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) vsum[c] = red[0];
+    __syncthreads();
+  }
   if (threadIdx.x < 9) {
     const int k = threadIdx.x / 3, l = threadIdx.x % 3;
-    // (virial.t() + virial)/2 : models/lammps_ani.py:200
-    a.ev_out[1 + threadIdx.x] =
-        a.virial_acc ? 0.5 * (a.virial_acc[3 * k + l] + a.virial_acc[3 * l + k]) * 627.5094738898777 : 0.0;
+    a.ev_out[1 + threadIdx.x] = 0.5 * (vsum[3 * k + l] + vsum[3 * l + k]) * 627.5094738898777;
   }
 }
 
