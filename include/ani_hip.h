@@ -37,7 +37,9 @@ typedef struct ani_handle ani_handle;
 /*
  * Replaces ANI::ANI(model_file, local_rank, use_num_models, use_cuaev, use_fullnbr, use_single)
  * (src/ani_csrc/ani.h:31-36, src/ani_csrc/ani.cpp:35-97).
- *   model_file      flat model file (lammps-ani_amd/model_file.py), not a TorchScript archive
+ *   model_file      flat model file (lammps-ani_amd/model_file.py), not a TorchScript archive; an optional trailing block
+ *                   carries the tables of the pairwise repulsion the reference attaches to reactive models
+ *                   (models/ani_models.py:50-53), which is then added to energy, forces and virial
  *   local_rank      HIP device ordinal (the reference maps node-local rank % device count, src/pair_ani.cpp:255-283);
  *                   -1 = cpu is refused
  *   use_num_models  first n ensemble members, -1 = all (models/lammps_ani.py:332-343)

@@ -42,7 +42,7 @@ def _find(sd: Mapping[str, object], suffix: str) -> np.ndarray:
 
 
 def from_state_dict(sd: Mapping[str, object], species: Sequence[str], rcr: float = 5.1, rca: float = 3.5,
-                    celu_alpha: float = 0.1) -> AniModel:
+                    celu_alpha: float = 0.1, rep_cutoff: float = None) -> AniModel:
     """Build an :class:`AniModel` from a torchani-style state dict.  ``species`` is the model's species order
     (= LAMMPS type order, ``src/pair_ani.cpp:110``)."""
     species = list(species)
@@ -71,6 +71,13 @@ def from_state_dict(sd: Mapping[str, object], species: Sequence[str], rcr: float
         raise ValueError(f"{sae.shape[0]} self energies for {len(species)} species")
 
     model = AniModel(species, float(rcr), float(rca), eta_r, eta_a, zeta, shf_r, shf_a, shf_z, sae, [], [], celu_alpha)
+    # optional pairwise repulsion (RepulsionXTB buffers; its cutoff is a Python attribute there: pass rep_cutoff)
+    rep_keys = [k for k in sd if k.endswith("y_ab")]
+    if rep_keys and rep_cutoff is not None:
+        pre = rep_keys[0][: -len("y_ab")]
+        model.repulsion = {"cutoff": float(rep_cutoff), "y_ab": _np(sd[pre + "y_ab"]).astype(np.float64),
+                           "sqrt_alpha_ab": _np(sd[pre + "sqrt_alpha_ab"]).astype(np.float64),
+                           "k_rep_ab": _np(sd[pre + "k_rep_ab"]).astype(np.float64)}
     dims: List[List[int]] = []
     for s in species:
         layers = [nets[0][s][i] for i in sorted(nets[0][s])]
@@ -100,6 +107,9 @@ def to_state_dict(m: AniModel) -> Dict[str, np.ndarray]:
         "aev_computer.ShfA": np.asarray(m.ShfA).reshape(1, 1, -1, 1), "aev_computer.ShfZ": np.asarray(m.ShfZ).reshape(1, 1, 1, -1),
         "energy_shifter.self_energies": np.asarray(m.self_energies),
     }
+    if m.repulsion is not None:
+        for key in ("y_ab", "sqrt_alpha_ab", "k_rep_ab"):
+            sd["rep_calc." + key] = np.asarray(m.repulsion[key])
     for mi in range(m.num_models):
         for si, sym in enumerate(m.species):
             for li, (W, b) in enumerate(m.weights[mi][si]):
@@ -116,12 +126,14 @@ def main(argv=None):
     ap.add_argument("--rcr", type=float, default=5.1)
     ap.add_argument("--rca", type=float, default=3.5)
     ap.add_argument("--celu-alpha", type=float, default=0.1)
+    ap.add_argument("--rep-cutoff", type=float, default=None,
+                    help="also convert the RepulsionXTB tables found in the state dict, with this cutoff (5.1 in the reference)")
     a = ap.parse_args(argv)
     import torch
     sd = torch.load(a.state_dict, map_location="cpu")
     if hasattr(sd, "state_dict"):
         sd = sd.state_dict()
-    m = from_state_dict(sd, a.species, a.rcr, a.rca, a.celu_alpha)
+    m = from_state_dict(sd, a.species, a.rcr, a.rca, a.celu_alpha, a.rep_cutoff)
     write_model(a.out, m)
     print(f"wrote {a.out}: {m.num_species} species, {m.num_models} members, AEV {m.aev_len}, dims {m.dims[0]}")
 

@@ -96,6 +96,7 @@ struct ani_handle {
   DevBuf<float4> xyzs;
   DevBuf<int4> row_info;
   DevBuf<double> x64, f64, ev, eatom, partial, virial_acc;
+  DevBuf<double> rep_tables, erep;  // optional pairwise repulsion: tables of the model file, energy partial sums
   DevBuf<float> aev, gaev, act, e_rows, fbuf;
   DevBuf<double> aev64, gaev64, act64, e_rows64, fbuf64;  // precision 'double'
   DevBuf<int> nb_cell_id, nb_cell_count, nb_cell_start, nb_cursor, nb_order;  // device-side list build (row f1)
@@ -216,6 +217,10 @@ int upload_model(ani_handle* h) {
       rc = mirror64(h, &n.w_out64, n.w_out, w.size()); if (rc) return rc;
       rc = mirror64(h, &n.b_out64, n.b_out, b.size()); if (rc) return rc;
     }
+  }
+  if (m.has_rep) {
+    HIP_TRY(h, h->rep_tables.reserve(m.rep_tables.size()));
+    HIP_TRY(h, hipMemcpy(h->rep_tables.p, m.rep_tables.data(), sizeof(double) * m.rep_tables.size(), hipMemcpyHostToDevice));
   }
   AevParams& p = h->ap;
   memset(&p, 0, sizeof(p));
@@ -550,10 +555,20 @@ int run_step64(ani_handle* h, const double* d_x, int eflag_atom, int vflag, doub
     }
   }
   launch_aev64_backward(p, a, st);
+  if (m.has_rep) {
+    HIP_TRY(h, h->erep.reserve(kVirialSlots));
+    HIP_TRY(h, hipMemsetAsync(h->erep.p, 0, sizeof(double) * kVirialSlots, st));
+    RepArgs ra{};
+    ra.row_info = h->row_info.p; ra.nrows = h->nrows; ra.jlist = h->jlist.p; ra.species = h->species.p;
+    ra.pos = d_x; ra.fbuf = h->fbuf64.p; ra.virial = vflag ? h->virial_acc.p : nullptr; ra.erep = h->erep.p;
+    ra.tables = h->rep_tables.p; ra.S = m.S; ra.nslots = kVirialSlots; ra.vslots = 1; ra.cutoff = m.rep_cut;
+    launch_repulsion(ra, true, st);
+  }
   Sae64 sae{};
   for (int s = 0; s < m.S; s++) sae.v[s] = m.sae[s];
   launch_finish64(h->e_rows64.p, M, h->nrows, h->centre_of_row.p, h->ilist.p, h->species.p, sae, h->fbuf64.p, h->ntotal,
                   vflag ? h->virial_acc.p : nullptr, d_f, f_accumulate, d_ev, eflag_atom ? d_eatom : nullptr, h->err_flag.p, st);
+  if (m.has_rep) launch_repulsion_energy(h->erep.p, kVirialSlots, d_ev, st);
   HIP_TRY(h, hipGetLastError());
   return ANI_OK;
 }
@@ -591,6 +606,15 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   compute_mlp(h, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[2], st));
   launch_aev_backward(h->ap_run, a, h->max_numneigh, st);
+  if (m.has_rep) {
+    HIP_TRY(h, h->erep.reserve(kVirialSlots));
+    HIP_TRY(h, hipMemsetAsync(h->erep.p, 0, sizeof(double) * kVirialSlots, st));
+    RepArgs ra{};
+    ra.row_info = h->row_info.p; ra.nrows = h->nrows; ra.jlist = h->jlist.p; ra.species = h->species.p;
+    ra.pos = d_x; ra.fbuf = h->fbuf.p; ra.virial = vflag ? h->virial_acc.p : nullptr; ra.erep = h->erep.p;
+    ra.tables = h->rep_tables.p; ra.S = m.S; ra.nslots = kVirialSlots; ra.vslots = kVirialSlots; ra.cutoff = m.rep_cut;
+    launch_repulsion(ra, false, st);
+  }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[3], st));
 
   FinishArgs fa{};
@@ -604,6 +628,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   fa.partial = h->partial.p;
   fa.err_flag = h->err_flag.p;
   launch_finish(fa, st);
+  if (m.has_rep) launch_repulsion_energy(h->erep.p, kVirialSlots, d_ev, st);
   if (h->timing) {
     HIP_TRY(h, hipEventRecord(h->evt[4], st));
   }
@@ -705,6 +730,7 @@ void ani_destroy(ani_handle* h) {
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
   h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
   h->xyzs.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release();
+  h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();
   for (auto& e : h->evt_pool) if (e) (void)hipEventDestroy(e);

@@ -113,6 +113,23 @@ void launch_nbr_count(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch
 void launch_nbr_fill(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, const int* d_nbr_off,
                      int* d_jlist, int* d_ilist, hipStream_t st);
 
+// optional pairwise repulsion (ani_kernels_rep.hip)
+struct RepArgs {
+  const int4* row_info;   // [nrows] {centre atom, list begin, list length, ii}
+  int nrows;
+  const int* jlist;
+  const int* species;     // [ntotal] model species
+  const double* pos;      // [ntotal*3] positions as handed in by the caller (fp64 in both precisions)
+  void* fbuf;             // fp32 path: float4[ntotal] accumulators; fp64 path: double[ntotal*3]
+  double* virial;         // [vslots][9] or NULL
+  double* erep;           // [nslots] energy partial sums (Hartree), zeroed by the caller
+  const double* tables;   // device: y_ab[S*S], sqrt_alpha_ab[S*S], k_rep_ab[S*S]
+  int S, nslots, vslots;  // slot counts are powers of two
+  double cutoff;          // Angstrom
+};
+void launch_repulsion(const RepArgs& a, bool fp64, hipStream_t st);
+void launch_repulsion_energy(const double* erep, int nslots, double* d_ev, hipStream_t st);
+
 // energy reduction (+ self energies), per-centre energies, force conversion
 struct FinishArgs {
   const float* e_rows;   // [M][nrows_ld] per-member row energies (already scaled by 1/M)

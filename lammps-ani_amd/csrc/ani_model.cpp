@@ -86,11 +86,20 @@ std::string load_model(const std::string& path, int use_num_models, HostModel& m
       }
     }
   }
-  char extra;
-  bool trailing = fread(&extra, 1, 1, f) == 1;
+  if (!r.ok) { fclose(f); return "model file truncated (weights)"; }
+  char tag[8];
+  const size_t ntag = fread(tag, 1, 8, f);
+  if (ntag != 0 && ntag != 8) { fclose(f); return "model file has trailing bytes"; }
+  if (ntag == 8) {   // optional trailing block: pairwise repulsion tables
+    if (memcmp(tag, "REPULXTB", 8) != 0) { fclose(f); return "model file has trailing bytes"; }
+    m.rep_tables.resize((size_t)3 * m.S * m.S);
+    r.get(&m.rep_cut, 1);
+    r.get(m.rep_tables.data(), m.rep_tables.size());
+    char extra;
+    if (!r.ok || fread(&extra, 1, 1, f) == 1) { fclose(f); return "model file: malformed repulsion block"; }
+    m.has_rep = true;
+  }
   fclose(f);
-  if (!r.ok) return "model file truncated (weights)";
-  if (trailing) return "model file has trailing bytes";
   return "";
 }
 

@@ -24,6 +24,10 @@ struct HostModel {
   // W[m][s][l] row-major [out][in]; b[m][s][l] [out]
   std::vector<std::vector<std::vector<std::vector<float>>>> W, b;
   int radial_len = 0, angular_len = 0, aev_len = 0;
+  // optional pairwise repulsion block of the model file: [S*S] tables in atomic units, cutoff in Angstrom
+  bool has_rep = false;
+  double rep_cut = 0;
+  std::vector<double> rep_tables;   // y_ab | sqrt_alpha_ab | k_rep_ab
 };
 
 // returns empty string on success, else the error text.  use_num_models < 0 = all (first-n semantics,

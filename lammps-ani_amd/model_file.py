@@ -20,6 +20,8 @@ Layout (all little-endian, no padding except where stated)::
     for m in models: for s in species: for l in layers:
         f32[dims[l+1]][dims[l]] W      (torch.nn.Linear layout: [out][in])
         f32[dims[l+1]]          b
+    optional trailing block (pairwise repulsion):
+        char[8] "REPULXTB" ; f64 cutoff (Angstrom) ; f64[S][S] y_ab ; f64[S][S] sqrt_alpha_ab ; f64[S][S] k_rep_ab
 
 Species order is the LAMMPS type order (type-1 = species index; ``src/pair_ani.cpp:110``).
 Weights of real ANI-2x are not available offline; :func:`synthetic_model` makes
@@ -53,6 +55,9 @@ class AniModel:
     # weights[m][s][l] -> (W [out,in] f32, b [out] f32)
     weights: list = field(default_factory=list)
     celu_alpha: float = 0.1
+    # optional pairwise repulsion (torchani RepulsionXTB as the reference attaches it, models/ani_models.py:50-53):
+    # dict(cutoff=float, y_ab=[S,S], sqrt_alpha_ab=[S,S], k_rep_ab=[S,S]); atomic units inside (Bohr, Hartree)
+    repulsion: dict = None
 
     @property
     def num_species(self) -> int:
@@ -89,6 +94,7 @@ class AniModel:
             "species", "Rcr", "Rca", "EtaR", "EtaA", "Zeta", "ShfR", "ShfA", "ShfZ",
             "self_energies", "dims", "celu_alpha")})
         out.weights = self.weights[:n]
+        out.repulsion = self.repulsion
         return out
 
 
@@ -114,6 +120,13 @@ def write_model(path: str, m: AniModel) -> None:
                     assert W.shape == (m.dims[s][l + 1], m.dims[s][l]) and b.shape == (m.dims[s][l + 1],)
                     f.write(np.ascontiguousarray(W, dtype="<f4").tobytes())
                     f.write(np.ascontiguousarray(b, dtype="<f4").tobytes())
+        if m.repulsion is not None:
+            f.write(b"REPULXTB")
+            f.write(struct.pack("<d", float(m.repulsion["cutoff"])))
+            for key in ("y_ab", "sqrt_alpha_ab", "k_rep_ab"):
+                a = np.ascontiguousarray(m.repulsion[key], dtype="<f8")
+                assert a.shape == (S, S), key
+                f.write(a.tobytes())
 
 
 def read_model(path: str) -> AniModel:
@@ -154,10 +167,18 @@ def read_model(path: str) -> AniModel:
                 per_l.append((W, b))
             per_s.append(per_l)
         weights.append(per_s)
+    rep = None
     if off != len(buf):
-        raise ValueError(f"{path}: trailing bytes ({len(buf) - off})")
+        if buf[off:off + 8] != b"REPULXTB" or len(buf) - off != 16 + 3 * 8 * S * S:
+            raise ValueError(f"{path}: trailing bytes ({len(buf) - off})")
+        off += 8
+        cutoff = struct.unpack_from("<d", buf, off)[0]
+        off += 8
+        rep = {"cutoff": cutoff}
+        for key in ("y_ab", "sqrt_alpha_ab", "k_rep_ab"):
+            rep[key] = arr(S * S, "<f8", 8).reshape(S, S)
     return AniModel(species, Rcr, Rca, EtaR, EtaA, Zeta, ShfR, ShfA, ShfZ,
-                    np.array(sae), dims, weights, alpha)
+                    np.array(sae), dims, weights, alpha, rep)
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -179,6 +200,26 @@ def _uniform_pm1(n: int, seed: int) -> np.ndarray:
     """n doubles uniform in [-1, 1)."""
     z = _splitmix64(n, seed)
     return (z >> np.uint64(11)).astype(np.float64) * (2.0 / (1 << 53)) - 1.0
+
+
+# GFN2-xTB repulsion parameters (alpha, effective nuclear charge) by element [RECALL: Bannwarth, Ehlert, Grimme, JCTC 15
+# (2019) SI; the values torchani's RepulsionXTB tabulates].  A converted real model carries its own tables; these feed
+# the synthetic models and tests.
+XTB_REP_ALPHA = {"H": 2.213717, "C": 1.247655, "N": 1.682689, "O": 2.165712, "F": 2.421394, "S": 1.214553, "Cl": 1.577144}
+XTB_REP_YEFF = {"H": 1.105388, "C": 4.231078, "N": 5.242592, "O": 5.784415, "F": 7.021486, "S": 14.995090, "Cl": 17.353134}
+
+
+def xtb_repulsion(species: Sequence[str], cutoff: float = 5.1) -> dict:
+    """Tables of ``RepulsionXTB(cutoff=5.1, symbols=..., cutoff_fn="smooth")`` (models/ani_models.py:53):
+    y_ab = y_a y_b, sqrt_alpha_ab = sqrt(alpha_a alpha_b), k_rep_ab = 1.5 except 1.0 for H-H."""
+    a = np.array([XTB_REP_ALPHA[s] for s in species])
+    y = np.array([XTB_REP_YEFF[s] for s in species])
+    k = np.full((len(species), len(species)), 1.5)
+    for i, si in enumerate(species):
+        for j, sj in enumerate(species):
+            if si == "H" and sj == "H":
+                k[i, j] = 1.0
+    return {"cutoff": float(cutoff), "y_ab": np.outer(y, y), "sqrt_alpha_ab": np.sqrt(np.outer(a, a)), "k_rep_ab": k}
 
 
 ANI2X_SPECIES = ["H", "C", "N", "O", "S", "F", "Cl"]
@@ -218,7 +259,7 @@ def _fill_weights(model: AniModel, num_models: int, seed: int, bias_scale: float
 
 
 def synthetic_model(kind: str = "ani2x", num_models: int = 8, seed: int = 2024,
-                    bias_scale: float = 0.05, out_scale: float = 0.2) -> AniModel:
+                    bias_scale: float = 0.05, out_scale: float = 0.2, repulsion: bool = False) -> AniModel:
     """Shape-identical stand-in for a trained model.
 
     ``kind``: ``"ani2x"`` (7 species, AEV 1008, nets of SURVEY.md §8a row a7), ``"ani1x"`` (4 species,
@@ -247,4 +288,6 @@ def synthetic_model(kind: str = "ani2x", num_models: int = 8, seed: int = 2024,
         raise ValueError(kind)
     m.dims = [[m.aev_len] + hid[s] + [1] for s in sp]
     _fill_weights(m, num_models, seed, bias_scale, out_scale)
+    if repulsion:
+        m.repulsion = xtb_repulsion(sp, cutoff=m.Rcr)
     return m

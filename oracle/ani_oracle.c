@@ -60,6 +60,10 @@ typedef struct {
   REAL* B[64][MAXS][MAXL];
   int radial_len, angular_len, aev_len;
   int triu[MAXS][MAXS];
+  /* optional pairwise repulsion (RepulsionXTB as attached in models/ani_models.py:50-53; called from
+   * models/lammps_ani.py:186-193,300-330).  Tables in atomic units. */
+  int has_rep;
+  double rep_cut, rep_y[MAXS][MAXS], rep_sa[MAXS][MAXS], rep_k[MAXS][MAXS];
   char err[256];
 } oracle_model;
 
@@ -121,6 +125,21 @@ oracle_model* ani_oracle_load(const char* path, int use_num_models) {
         free(b);
       }
   m->M = use_num_models;
+  { /* optional trailing block "REPULXTB": cutoff, y_ab, sqrt_alpha_ab, k_rep_ab */
+    char tag[8];
+    if (fread(tag, 1, 8, f) == 8) {
+      double buf[3 * MAXS * MAXS];
+      const int n = m->S * m->S;
+      if (memcmp(tag, "REPULXTB", 8) || rd(f, &m->rep_cut, 8) || rd(f, buf, 8 * 3 * (size_t)n)) goto fail;
+      for (int a = 0; a < m->S; a++)
+        for (int b = 0; b < m->S; b++) {
+          m->rep_y[a][b] = buf[a * m->S + b];
+          m->rep_sa[a][b] = buf[n + a * m->S + b];
+          m->rep_k[a][b] = buf[2 * n + a * m->S + b];
+        }
+      m->has_rep = 1;
+    }
+  }
   fclose(f);
   m->radial_len = m->S * m->nR;
   m->angular_len = m->S * (m->S + 1) / 2 * m->nA * m->nZ;
@@ -322,6 +341,28 @@ static void mlp_block(const oracle_model* m, int a, int s, int nb, const REAL* X
  * eatom [ncentre] kcal/mol (in centre order), virial [9] kcal/mol row-major, aev_out [ncentre*aev_len],
  * gaev_out [ncentre*aev_len] (dE/dAEV in Hartree).
  */
+/*
+ * Pair repulsion e(r) and de/dr (Hartree, Hartree/Angstrom), restating torchani's RepulsionXTB with the "smooth" cutoff
+ * [RECALL: torchani is not in the reference tree; only its construction and call sites are]:
+ *   d = r in Bohr;  e = y_ab / d * exp(-sqrt_alpha_ab * d^k_ab) * fc(r),  fc(r) = exp(1 - 1 / (1 - (r/Rc)^2)) for r < Rc.
+ * The caller adds HALF of it per (centre, neighbour) entry of the full list: a pair of two local atoms is seen from both
+ * ends, a local-ghost pair from one end only -- which is the ghost_flags weighting of compute_from_neighbors
+ * (models/lammps_ani.py:188-191) for a rank's share of the energy.
+ */
+static void rep_pair(const oracle_model* m, int sa, int sb, double r, double* e, double* de) {
+  const double A2B = 1.8897261258369282;
+  *e = 0; *de = 0;
+  if (r >= m->rep_cut) return;
+  const double x = r / m->rep_cut, den = 1.0 - x * x;
+  if (den <= 1e-10) return;
+  const double fc = exp(1.0 - 1.0 / den), dfc = fc * (-(2.0 * x / m->rep_cut) / (den * den));
+  const double d = r * A2B, y = m->rep_y[sa][sb], a = m->rep_sa[sa][sb], k = m->rep_k[sa][sb];
+  const double g = y / d * exp(-a * pow(d, k));
+  const double dg = A2B * g * (-1.0 / d - a * k * pow(d, k - 1.0));
+  *e = g * fc;
+  *de = dg * fc + g * dfc;
+}
+
 static int compute_core(const oracle_model* m, int ntotal, int ncentre, const int* centre, const int64_t* off, const int* nj,
                         const int64_t* species, const double* x, int compat, double* energy, double* force, double* eatom,
                         double* virial, REAL* aev_out, REAL* gaev_out) {
@@ -399,6 +440,18 @@ static int compute_core(const oracle_model* m, int ntotal, int ncentre, const in
       int i = centre[c];
       int n = gather(m, i, species, x, off + c, nj, compat, nb, rad, ang);
       aev_backward(m, n, nb, rad, ang, gaev + (size_t)c * A, gd);
+      if (m->has_rep) {
+        double er = 0;
+        for (int p = 0; p < n; p++) {
+          double e, de;
+          rep_pair(m, (int)species[i], nb[p].sp, (double)nb[p].r, &e, &de);
+          er += 0.5 * e;
+          if (de != 0)
+            for (int k = 0; k < 3; k++) gd[p][k] += (REAL)(0.5 * de * (double)nb[p].d[k] / (double)nb[p].r);
+        }
+#pragma omp atomic
+        etot += er;
+      }
       double fi[3] = {0, 0, 0};
       for (int p = 0; p < n; p++) {
         for (int k = 0; k < 3; k++) {

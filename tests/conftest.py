@@ -16,7 +16,7 @@ from lammps_ani_amd import model_file as mf  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 GOLDEN_CASES = ["water30_pbc_ani2x_m8", "water30_open_ani2x_m8", "mixed64_pbc_ani1x_m2", "mixed40_pbc_tiny_m3",
-                "mixed96_pbc_ani2x_m2"]
+                "mixed96_pbc_ani2x_m2", "mixed64_pbc_ani1x_m2_rep"]
 
 
 def pytest_configure(config):
@@ -29,11 +29,11 @@ def model_cache(tmp_path_factory):
     d = tmp_path_factory.mktemp("models")
     cache = {}
 
-    def get(kind, num_models, seed):
-        key = (kind, int(num_models), int(seed))
+    def get(kind, num_models, seed, repulsion=False):
+        key = (kind, int(num_models), int(seed), bool(repulsion))
         if key not in cache:
-            p = str(d / f"{kind}_m{num_models}_s{seed}.anim")
-            mf.write_model(p, mf.synthetic_model(kind, int(num_models), int(seed)))
+            p = str(d / f"{kind}_m{num_models}_s{seed}{'_rep' if repulsion else ''}.anim")
+            mf.write_model(p, mf.synthetic_model(kind, int(num_models), int(seed), repulsion=bool(repulsion)))
             cache[key] = p
         return cache[key]
 
@@ -58,7 +58,7 @@ def golden_input(g, half=False):
 
 
 def golden_model_path(g, model_cache):
-    p = model_cache(str(g["kind"]), int(g["num_models"]), int(g["seed"]))
+    p = model_cache(str(g["kind"]), int(g["num_models"]), int(g["seed"]), bool(int(g["repulsion"])) if "repulsion" in g else False)
     with open(p, "rb") as f:
         crc = zlib.crc32(f.read())
     assert crc == int(g["model_crc"]), "synthetic model generator drifted from the one the fixtures were made with"

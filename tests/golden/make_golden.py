@@ -143,6 +143,22 @@ def torch_reference(model: mf.AniModel, species: np.ndarray, x: np.ndarray, nloc
             acc = acc + h.flatten()
         atomic = atomic.index_add(0, idx, acc / model.num_models + float(model.self_energies[s]))
     energy = atomic.sum()
+    if model.repulsion is not None:
+        # pairwise repulsion on the half list (models/lammps_ani.py:186-193,300-330; RepulsionXTB with the "smooth" cutoff,
+        # atomic units inside): a pair with a ghost end counts half (ghost_flags), pairs of two ghosts are not in the list
+        rep = model.repulsion
+        i12, j12 = a12t[0], a12t[1]
+        inside = (dist < rep["cutoff"]).nonzero().flatten()
+        rr = dist.index_select(0, inside)
+        si, sj = sp.index_select(0, i12.index_select(0, inside)), sp.index_select(0, j12.index_select(0, inside))
+        y = torch.from_numpy(np.asarray(rep["y_ab"], dtype=np.float64))[si, sj]
+        sa = torch.from_numpy(np.asarray(rep["sqrt_alpha_ab"], dtype=np.float64))[si, sj]
+        kk = torch.from_numpy(np.asarray(rep["k_rep_ab"], dtype=np.float64))[si, sj]
+        d_bohr = rr * 1.8897261258369282
+        fc = torch.exp(1.0 - 1.0 / (1.0 - (rr / rep["cutoff"]) ** 2).clamp(min=1e-10))
+        w = torch.where((i12.index_select(0, inside) < nlocal) & (j12.index_select(0, inside) < nlocal),
+                        torch.ones_like(rr), 0.5 * torch.ones_like(rr))
+        energy = energy + (w * y / d_bohr * torch.exp(-sa * d_bohr ** kk) * fc).sum()
     gx, gdiff = torch.autograd.grad([energy], [coords, diff])
     virial = gdiff.t() @ diff
     virial = -(virial.t() + virial) / 2
@@ -167,6 +183,8 @@ CASES = [
     ("mixed64_pbc_ani1x_m2", lambda: hx.random_box(64, 4, 9.0, seed=11), "ani1x", 2, 7),
     ("mixed40_pbc_tiny_m3", lambda: hx.random_box(40, 3, 8.0, seed=5), "tiny", 3, 3),
     ("mixed96_pbc_ani2x_m2", lambda: hx.random_box(96, 7, 10.5, seed=23), "ani2x", 2, 99),
+    # with the optional pairwise repulsion block
+    ("mixed64_pbc_ani1x_m2_rep", lambda: hx.random_box(64, 4, 9.0, seed=11), "ani1x", 2, 7, True),
 ]
 
 
@@ -177,13 +195,14 @@ def _open(s):
 
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
-    for name, factory, kind, M, seed in CASES:
+    for name, factory, kind, M, seed, *opt in CASES:
+        rep_flag = bool(opt and opt[0])
         sys_ = factory()
-        model = mf.synthetic_model(kind, M, seed)
+        model = mf.synthetic_model(kind, M, seed, repulsion=rep_flag)
         full = hx.decompose(sys_, cutoff=model.Rcr, skin=2.0, half=False)
         half = hx.decompose(sys_, cutoff=model.Rcr, skin=2.0, half=True)
         a12 = half.atom_index12().reshape(2, -1)
-        rec = dict(kind=kind, num_models=M, seed=seed, model_crc=model_crc(model),
+        rec = dict(kind=kind, num_models=M, seed=seed, repulsion=int(rep_flag), model_crc=model_crc(model),
                    sys_x=sys_.x, sys_types=sys_.types, boxlo=sys_.boxlo, boxhi=sys_.boxhi,
                    periodic=np.array(sys_.periodic, dtype=np.int32), cutoff=model.Rcr, skin=2.0,
                    nlocal=full.nlocal, x=full.x, types=full.types, numneigh=full.numneigh, jlist=full.jlist,

@@ -20,6 +20,16 @@ def test_state_dict_round_trip(kind, nm, tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
 
 
+def test_repulsion_tables_round_trip(tmp_path):
+    m = mf.synthetic_model("ani1x", 1, seed=2, repulsion=True)
+    m2 = cv.from_state_dict(cv.to_state_dict(m), m.species, m.Rcr, m.Rca, rep_cutoff=m.repulsion["cutoff"])
+    a, b = str(tmp_path / "a.anim"), str(tmp_path / "b.anim")
+    mf.write_model(a, m)
+    mf.write_model(b, m2)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert cv.from_state_dict(cv.to_state_dict(m), m.species, m.Rcr, m.Rca).repulsion is None   # only on request
+
+
 def test_cli_and_single_network_layout(tmp_path):
     m = mf.synthetic_model("tiny", 1, seed=4)
     sd = {k.replace("neural_networks.0.", "neural_networks."): torch.as_tensor(v) for k, v in cv.to_state_dict(m).items()}

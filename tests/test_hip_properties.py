@@ -177,3 +177,28 @@ def test_screened_radial_capacity_overflow_is_loud_and_option_restores_it(model_
     got2 = ani.compute(inp2, ago=0)
     assert np.abs(got2["force"] - got["force"]).max() < 1e-4
     ani.close()
+
+
+def test_repulsion_term_rank_invariance_and_oracle(model_cache, hip):
+    """Optional pairwise repulsion (model-file block REPULXTB): an owned-ghost pair counts half on each rank, so the
+    per-rank energies still sum to the single-rank energy; forces and virial against the oracle in both precisions."""
+    from oracle import Oracle
+    p = model_cache("ani1x", 2, 7, True)
+    p0 = model_cache("ani1x", 2, 7)
+    sysm = hx.random_box(900, 4, 24.0, seed=3, min_dist=1.0)
+    one = hx.decompose(sysm)
+    ref = Oracle(p).compute(one)
+    for single in (True, False):
+        ani = hip.ANI(p, 0, use_single=single)
+        r1 = ani.compute(one, ago=0)
+        tol = F_TOL if single else 1e-7
+        assert np.abs(r1["force"] - ref["force"]).max() < tol
+        assert abs(r1["energy"] - ref["energy"]) < (2e-2 if single else 1e-6)
+        assert np.abs(r1["virial"] - ref["virial"]).max() < (0.2 if single else 1e-6)
+        e = sum(ani.compute(hx.decompose(sysm, (2, 2, 1), rank), ago=0)["energy"] for rank in range(4))
+        assert abs(e - r1["energy"]) < (2e-2 if single else 1e-6)
+        ani.close()
+    # the block really adds something: same weights without it differ
+    base = hip.ANI(p0, 0)
+    assert abs(base.compute(one, ago=0)["energy"] - ref["energy"]) > 1.0
+    base.close()
