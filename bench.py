@@ -61,9 +61,9 @@ def aev_bytes_per_step(A, nlocal, ntotal, npairs):
 class Workload:
     """One water box on this rank: system, decomposition, device tensors, library handle, ghost exchange."""
 
-    def __init__(self, atoms, models, aev, rank, world, dev, dev_index, vflag):
+    def __init__(self, atoms, models, aev, rank, world, dev, dev_index, vflag, repulsion=False):
         self.atoms, self.models, self.world, self.vflag = atoms, models, world, vflag
-        self.model = mf.synthetic_model("ani2x", models, seed=2024)
+        self.model = mf.synthetic_model("ani2x", models, seed=2024, repulsion=repulsion)
         self.mpath = f"/tmp/bench_ani2x_m{models}_r{rank}.anim"
         mf.write_model(self.mpath, self.model)
         # LAMMPS sorts atoms spatially (atom_modify sort): neighbours are then close in memory
@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--no-dense-pass", action="store_true", help="skip the extra timed pass with the full-width AEV")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configuration (10 002 atoms, 8 members)")
     ap.add_argument("--no-md", action="store_true", help="skip the full-MD-loop pass (device neighbour list + integrator)")
+    ap.add_argument("--repulsion", action="store_true", help="model with the optional pairwise repulsion block (not the headline configuration)")
     ap.add_argument("--md-steps", type=int, default=200)
     args = ap.parse_args()
 
@@ -192,7 +193,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    wl = Workload(args.atoms, args.models, args.aev, rank, world, dev, dev_index, args.vflag)
+    wl = Workload(args.atoms, args.models, args.aev, rank, world, dev, dev_index, args.vflag, args.repulsion)
     ani, inp, model, system = wl.ani, wl.inp, wl.model, wl.system
     if args.dense_aev:
         ani.set_option("prune_absent_species", 0)

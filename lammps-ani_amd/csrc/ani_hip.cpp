@@ -605,10 +605,29 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[1], st));
   compute_mlp(h, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[2], st));
-  launch_aev_backward(h->ap_run, a, h->max_numneigh, st);
   if (m.has_rep) {
     HIP_TRY(h, h->erep.reserve(kVirialSlots));
     HIP_TRY(h, hipMemsetAsync(h->erep.p, 0, sizeof(double) * kVirialSlots, st));
+  }
+  // the fast backward kernel applies the repulsion in its radial stage (tables by compact species, like the AEV layout);
+  // the generic kernel does not, and then the stand-alone kernel adds it
+  RepTab rt{};
+  if (m.has_rep && h->ap_run.S <= 8) {
+    rt.on = 1; rt.cutoff = (float)m.rep_cut; rt.erep = h->erep.p; rt.x64 = d_x;
+    std::vector<int> act;
+    for (int s = 0; s < m.S; s++) if (h->active_mask & (1 << s)) act.push_back(s);
+    if ((int)act.size() != h->ap_run.S) { act.clear(); for (int s = 0; s < m.S; s++) act.push_back(s); }
+    const size_t n2 = (size_t)m.S * m.S;
+    for (size_t ca = 0; ca < act.size(); ca++)
+      for (size_t cb = 0; cb < act.size(); cb++) {
+        const size_t src = (size_t)act[ca] * m.S + act[cb];
+        rt.y[8 * ca + cb] = (float)m.rep_tables[src];
+        rt.sa[8 * ca + cb] = (float)m.rep_tables[n2 + src];
+        rt.k[8 * ca + cb] = (float)m.rep_tables[2 * n2 + src];
+      }
+  }
+  const bool rep_done = launch_aev_backward(h->ap_run, a, h->max_numneigh, st, rt.on ? &rt : nullptr) && rt.on;
+  if (m.has_rep && !rep_done) {
     RepArgs ra{};
     ra.row_info = h->row_info.p; ra.nrows = h->nrows; ra.jlist = h->jlist.p; ra.species = h->species.p;
     ra.pos = d_x; ra.fbuf = h->fbuf.p; ra.virial = vflag ? h->virial_acc.p : nullptr; ra.erep = h->erep.p;

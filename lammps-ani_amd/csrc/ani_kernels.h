@@ -86,7 +86,19 @@ struct AevArgs {
 };
 // max_numneigh (known at rebuild) sizes the per-centre LDS neighbour lists of the fast path
 void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st);
-void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st);
+// optional pairwise repulsion folded into the radial stage of the fast backward kernel (tables indexed by the compact
+// species of the run, like the AEV layout); `on` = 0: none.  Returns true if the kernel that ran applied it (the fast
+// path); false: the caller adds it with launch_repulsion.
+struct RepTab {
+  int on;
+  float cutoff;
+  float y[64], sa[64], k[64];   // [8][8], atomic units
+  double* erep;                 // [kVirialSlots] energy partial sums (Hartree)
+  const double* x64;            // [ntotal*3] the caller's fp64 positions: pair distances of this steep term are taken
+                                // from them (a float position in a 100 A box is 4e-6 A off, worth 4e-3 kcal/mol/A
+                                // of force on a bonded O-H pair)
+};
+bool launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st, const RepTab* rep = nullptr);
 bool aev_fast_path(const AevParams& p, int max_numneigh);
 // rebuild time: stable sort of every centre's neighbour segment by neighbour species (jin -> jout)
 void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_numneigh, const int* d_jin, int* d_jout,

@@ -592,7 +592,8 @@ __global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, Aev
 
 template <int NA, int NZ, int NCH, int GR>
 __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row,
-                                                const Prefetched<NCH>& pf, const float4 (&grow)[GR], int lane, float (&wv)[9]) {
+                                                const Prefetched<NCH>& pf, const float4 (&grow)[GR], int lane, float (&wv)[9],
+                                                const RepTab& rep, float& er) {
   constexpr int NR = 16;
   const int4 info = pf.info;
 #pragma unroll
@@ -627,9 +628,33 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
         dEdr = fmaf(gg[k] * e, fmaf(-2.f * p.EtaR * dr, fc, dfc), dEdr);
       }
       const float sc = 0.25f * dEdr * frcp(r);
-      L.gd[3 * t + 0] = sc * L.rdx[t];
-      L.gd[3 * t + 1] = sc * L.rdy[t];
-      L.gd[3 * t + 2] = sc * L.rdz[t];
+      float gx = sc * L.rdx[t], gy = sc * L.rdy[t], gz = sc * L.rdz[t];
+      if (rep.on && r < rep.cutoff) {
+        // pairwise repulsion (ani_kernels_rep.hip has the formulas): half of e(r) per list entry.  The pair function in
+        // fp32 like the rest of this precision mode, but its argument from the fp64 positions: the wall is steep
+        const int ti = 8 * __float_as_int(pf.xi.w) + s;
+        const double* xj = rep.x64 + 3 * (long long)L.rj[t];
+        const double* xc = rep.x64 + 3 * (long long)info.x;
+        const double ddx = xj[0] - xc[0], ddy = xj[1] - xc[1], ddz = xj[2] - xc[2];
+        const double r64 = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+        const float rr = (float)r64;
+        const float x = rr * frcp(rep.cutoff), den = 1.f - x * x;
+        if (den > 1e-10f) {
+          const float fcr = fexp2((1.f - frcp(den)) * kLog2e);
+          const float dfcr = fcr * (-(2.f * x * frcp(rep.cutoff)) * frcp(den * den));
+          const float db = rr * 1.8897261258369282f, al = rep.sa[ti], kk = rep.k[ti];
+          const float pk1 = fexp2((kk - 1.f) * flog2(db));
+          const float g = rep.y[ti] * frcp(db) * fexp2(-al * pk1 * db * kLog2e);
+          const float dg = 1.8897261258369282f * g * (-frcp(db) - al * kk * pk1);
+          er += 0.5f * g * fcr;
+          const float sr = 0.5f * (dg * fcr + g * dfcr);
+          const double inv = 1.0 / r64;
+          gx += sr * (float)(ddx * inv); gy += sr * (float)(ddy * inv); gz += sr * (float)(ddz * inv);
+        }
+      }
+      L.gd[3 * t + 0] = gx;
+      L.gd[3 * t + 1] = gy;
+      L.gd[3 * t + 2] = gz;
     }
   }
   int nbk;
@@ -777,7 +802,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
 }
 
 template <int NA, int NZ, int NCH, int GR>
-__global__ __launch_bounds__(64 * kWavesB, 3) void aev_backward_fast(AevParams p, AevArgs a, int cap, int rowf) {
+__global__ __launch_bounds__(64 * kWavesB, 3) void aev_backward_fast(AevParams p, AevArgs a, int cap, int rowf, RepTab rep) {
   extern __shared__ float4 smem4[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, true, rowf), cap, true, rowf);
@@ -786,6 +811,7 @@ __global__ __launch_bounds__(64 * kWavesB, 3) void aev_backward_fast(AevParams p
   // younger prefetches in flight
   float4 grow[GR];
   float wv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this lane's share of the wave's virial
+  float er = 0.f;                                                // ... and of its repulsion energy
   const int n4 = p.aev_stride >> 2;
   ANI_PERSISTENT_LOOP(kWavesB, NCH,
                       {
@@ -793,7 +819,13 @@ __global__ __launch_bounds__(64 * kWavesB, 3) void aev_backward_fast(AevParams p
                         _Pragma("unroll") for (int c = 0; c < GR; c++) grow[c] =
                             (cur.info.x >= 0 && lane + 64 * c < n4) ? g4[lane + 64 * c] : make_float4(0, 0, 0, 0);
                       },
-                      (backward_centre<NA, NZ, NCH, GR>(p, a, cap, L, row, cur, grow, lane, wv)))
+                      (backward_centre<NA, NZ, NCH, GR>(p, a, cap, L, row, cur, grow, lane, wv, rep, er)))
+  if (rep.on) {
+    double se = (double)er;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
+    if (lane == 0) atomicAdd(&rep.erep[(blockIdx.x * kWavesB + wave) & (kVirialSlots - 1)], se);
+  }
   if (a.virial) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -1089,11 +1121,13 @@ static int persistent_blocks(K kernel, int nrows, int waves_per_block, size_t ld
   return need < fit ? need : fit;
 }
 
-template <typename K>
-static void launch_fast(K kernel, const AevParams& p, const AevArgs& a, int waves, size_t lds, int cap, int rowf, hipStream_t st) {
+template <typename K, typename... Extra>
+static void launch_fast(K kernel, const AevParams& p, const AevArgs& a, int waves, size_t lds, int cap, int rowf, hipStream_t st,
+                        Extra... extra) {
   // raising the dynamic-LDS limit is per kernel; every instantiation passes through here once
   (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.nrows, waves, lds)), dim3(64 * waves), lds, st, p, a, cap, rowf);
+  hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.nrows, waves, lds)), dim3(64 * waves), lds, st, p, a, cap, rowf,
+                     extra...);
 }
 
 void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
@@ -1113,15 +1147,17 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
   }
 }
 
-void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
-  if (a.nrows <= 0) return;
+bool launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st, const RepTab* rep) {
+  if (a.nrows <= 0) return true;
+  RepTab rt{};
+  if (rep) rt = *rep;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
   if (aev_fast_path(p, max_numneigh)) {
     const int cap = radial_cap(p, max_numneigh);
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, true, rowf) * 4 * kWavesB;
     const bool k1 = fast_kind(p) == 1, n3 = max_numneigh <= 192, g1 = p.aev_stride <= 256;
-#define ANI_BWD_CASE(NA, NZ, NCH, GR) launch_fast(aev_backward_fast<NA, NZ, NCH, GR>, p, a, kWavesB, lds, cap, rowf, st)
+#define ANI_BWD_CASE(NA, NZ, NCH, GR) launch_fast(aev_backward_fast<NA, NZ, NCH, GR>, p, a, kWavesB, lds, cap, rowf, st, rt)
     if (k1) {
       if (n3 && g1) ANI_BWD_CASE(8, 4, 3, 1);
       else if (n3) ANI_BWD_CASE(8, 4, 3, 4);
@@ -1134,9 +1170,10 @@ void launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
       else ANI_BWD_CASE(4, 8, 4, 4);
     }
 #undef ANI_BWD_CASE
-  } else {
-    hipLaunchKernelGGL(aev_backward_generic, grid, block, 0, st, p, a);
+    return true;
   }
+  hipLaunchKernelGGL(aev_backward_generic, grid, block, 0, st, p, a);
+  return false;
 }
 
 }  // namespace ani

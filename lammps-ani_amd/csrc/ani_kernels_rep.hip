@@ -42,15 +42,33 @@ __global__ __launch_bounds__(256) void repulsion_kernel(RepArgs a) {
     const double d[3] = {pj[0] - xi[0], pj[1] - xi[1], pj[2] - xi[2]};
     const double r = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     if (r >= a.cutoff || r <= 0.0) continue;
-    const double x = r / a.cutoff, den = 1.0 - x * x;
-    if (den <= 1e-10) continue;
     const int sj = a.species[j];
-    const double fc = exp(1.0 - 1.0 / den), dfc = fc * (-(2.0 * x / a.cutoff) / (den * den));
-    const double db = r * kAng2Bohr, al = tsa[sj], kk = tk[sj];
-    const double g = ty[sj] / db * exp(-al * pow(db, kk));
-    const double dg = kAng2Bohr * g * (-1.0 / db - al * kk * pow(db, kk - 1.0));
-    er += 0.5 * g * fc;
-    const double sc = 0.5 * (dg * fc + g * dfc) / r;   // dE/d(d_k) = sc * d_k  (Hartree/Angstrom)
+    double e_half, sc;   // half the pair energy (Hartree); dE/d(d_k) = sc * d_k (Hartree/Angstrom^2 * Angstrom)
+    if constexpr (sizeof(F) == 4) {
+      // precision 'single': r comes from the fp64 positions, the pair function itself in fp32 with the hardware
+      // exp2/log2 (the fp64 libm pow/exp made this kernel cost more than the whole AEV backward)
+      const float rf = (float)r, rc = (float)a.cutoff;
+      const float x = rf / rc, den = 1.f - x * x;
+      if (den <= 1e-10f) continue;
+      const float fc = __builtin_amdgcn_exp2f((1.f - 1.f / den) * 1.4426950408889634f);
+      const float dfc = fc * (-(2.f * x / rc) / (den * den));
+      const float db = rf * (float)kAng2Bohr, al = (float)tsa[sj], kk = (float)tk[sj];
+      const float pk1 = __builtin_amdgcn_exp2f((kk - 1.f) * __builtin_amdgcn_logf(db));   // db^(k-1)
+      const float g = (float)ty[sj] / db * __builtin_amdgcn_exp2f(-al * pk1 * db * 1.4426950408889634f);
+      const float dg = (float)kAng2Bohr * g * (-1.f / db - al * kk * pk1);
+      e_half = 0.5 * (double)(g * fc);
+      sc = 0.5 * (double)(dg * fc + g * dfc) / r;
+    } else {
+      const double x = r / a.cutoff, den = 1.0 - x * x;
+      if (den <= 1e-10) continue;
+      const double fc = exp(1.0 - 1.0 / den), dfc = fc * (-(2.0 * x / a.cutoff) / (den * den));
+      const double db = r * kAng2Bohr, al = tsa[sj], kk = tk[sj];
+      const double g = ty[sj] / db * exp(-al * pow(db, kk));
+      const double dg = kAng2Bohr * g * (-1.0 / db - al * kk * pow(db, kk - 1.0));
+      e_half = 0.5 * g * fc;
+      sc = 0.5 * (dg * fc + g * dfc) / r;
+    }
+    er += e_half;
     double gk[3] = {sc * d[0], sc * d[1], sc * d[2]};
     if constexpr (sizeof(F) == 4) {
       float* fb = reinterpret_cast<float*>(a.fbuf) + 4 * (long long)j;
