@@ -2,7 +2,7 @@
 """bench.py — throughput of the ANI pair-style hot path on MI355X, one process per GPU.
 
 A "step" is one pass of the hot path (what PairANI::compute does each MD step, src/pair_ani.cpp:66-233) over a
-synthetic water box resident in HBM: zero forces -> AEV forward -> MLP ensemble forward/backward (fp32 MFMA) ->
+synthetic water box resident in HBM: zero forces -> AEV forward -> MLP ensemble forward/backward (fp32 via split-bf16 MFMA) ->
 AEV backward (forces on local+ghost atoms) -> ghost-force reverse exchange (index_add on one rank, RCCL
 all_to_all_single between ranks).  ns/day = steps/s * 0.0432 at the reference's 0.5 fs timestep
 (examples/benchmark/run_one.py:100, read_perf.py:26-32).  The neighbour list is built once (ago = 0, untimed) and

@@ -6,7 +6,7 @@
 //                  128 per species so that every GEMM tile is species-pure)            (ani.cpp:213-229)
 //   pack           double positions -> float4 {x,y,z,species}                          (ani.cpp:206-209)
 //   AEV forward    -> aev[nrows][aev_stride], rows in species-bucket order             (lammps_ani.py:174)
-//   MLP            forward + input-gradient backward on fp32 MFMA -> e_rows, gaev      (lammps_ani.py:182-184,197)
+//   MLP            forward + input-gradient backward on MFMA (fp32 products as six bf16 terms, or fp32-input MFMA) -> e_rows, gaev      (lammps_ani.py:182-184,197)
 //   AEV backward   gaev -> forces on local+ghost atoms, virial                         (lammps_ani.py:195-216)
 //   finish         fp64 energy sum + self energies, kcal/mol conversion                (ani.cpp:246-262)
 #include "../../include/ani_hip.h"
