@@ -77,6 +77,8 @@ struct ani_handle {
   SpeciesMap cmap{};  // species -> index among the species present
   int active_mask = -1;
   bool prune = true;  // ani_set_option("prune_absent_species")
+  bool mlp_chain = true;   // ani_set_option("mlp_chain"): one chained launch for the MLP of small systems
+  ChainPlan chain_plan;
   bool mlp_split = true;  // ani_set_option("mlp_split_bf16"): six bf16 MFMA products per fp32 product instead of fp32-input MFMA
   std::vector<int> colmap;  // ap_run column -> ap column
   int device = 0;
@@ -401,6 +403,9 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
   const float alpha = (float)m.alpha, inv_alpha = (float)(1.0 / m.alpha);
   std::vector<GemmArgs> probs;
   probs.reserve(m.S);
+  // every layer's problems and epilogue, in launch order: either six grouped launches or one chained launch
+  std::vector<std::vector<GemmArgs>> layer_probs;
+  std::vector<int> layer_epi;
   auto base_args = [&](int s) {
     GemmArgs g{};
     g.rows = round_up(h->count[s], kRowTile);
@@ -441,7 +446,7 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
       }
       probs.push_back(g);
     }
-    launch_gemm_group(probs.data(), (int)probs.size(), k == L - 2 ? EPI_LAST : EPI_CELU, st, h->mlp_split);
+    layer_probs.push_back(probs); layer_epi.push_back(k == L - 2 ? EPI_LAST : EPI_CELU);
   }
   // backward: dE/dh_{k-1} = G_k W[k-1] with G_k = dE/dh_k * celu'(z_k).  The celu' factor of a layer is applied when
   // its raw gradient is staged as the A operand of the next product (Amask = the stored activation H_k), not in the
@@ -463,7 +468,7 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
       g.C = h->Gbuf[s][k - 1]; g.ldc = M * n.w[k - 1]; g.sC = n.w[k - 1];
       probs.push_back(g);
     }
-    launch_gemm_group(probs.data(), (int)probs.size(), EPI_PLAIN, st, h->mlp_split);
+    layer_probs.push_back(probs); layer_epi.push_back(EPI_PLAIN);
   }
   // dE/dAEV = sum over members of G_1 W[0]  (members concatenated along K)
   probs.clear();
@@ -479,7 +484,23 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
     g.C = h->gaev.p + (size_t)h->row_start[s] * h->ap_run.aev_stride; g.ldc = h->ap_run.aev_stride;
     probs.push_back(g);
   }
-  launch_gemm_group(probs.data(), (int)probs.size(), EPI_PLAIN, st, h->mlp_split);
+  layer_probs.push_back(probs); layer_epi.push_back(EPI_PLAIN);
+
+  // small systems, one ensemble member, split-bf16 arithmetic: the whole MLP as one chained launch (a workgroup takes
+  // its 64-row tile through all layers); otherwise one grouped launch per layer
+  const int np = (int)layer_probs[0].size();
+  int tiles = 0;
+  for (const GemmArgs& g : layer_probs[0]) tiles += g.rows / 64;
+  bool chain = h->mlp_chain && h->mlp_split && M == 1 && np > 0 && tiles <= mlp_chain_slots();
+  for (const auto& lp : layer_probs) chain = chain && (int)lp.size() == np;
+  if (chain) {
+    std::vector<GemmArgs> flat;
+    for (const auto& lp : layer_probs) flat.insert(flat.end(), lp.begin(), lp.end());
+    launch_mlp_chain(flat.data(), layer_epi.data(), (int)layer_probs.size(), np, &h->chain_plan, st);
+  } else {
+    for (size_t l = 0; l < layer_probs.size(); l++)
+      launch_gemm_group(layer_probs[l].data(), (int)layer_probs[l].size(), (Epilogue)layer_epi[l], st, h->mlp_split);
+  }
 }
 
 
@@ -752,6 +773,7 @@ void ani_destroy(ani_handle* h) {
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();
+  free_chain_plan(h->chain_plan);
   for (auto& e : h->evt_pool) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -948,6 +970,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
     h->prune = value != 0;
     h->have_list = false;  // takes effect at the next rebuild (ago = 0), which the caller must issue
     h->active_mask = -1;
+    return ANI_OK;
+  }
+  if (strcmp(name, "mlp_chain") == 0) {
+    h->mlp_chain = value != 0;
     return ANI_OK;
   }
   if (strcmp(name, "mlp_split_bf16") == 0) {

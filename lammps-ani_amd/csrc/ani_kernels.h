@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 #include "ani_model.h"
 
@@ -47,6 +48,20 @@ void launch_gemm(const GemmArgs& g, Epilogue epi, hipStream_t st);
 // split_bf16 = true: fp32 products evaluated as six bf16 MFMA products of the exact three-way splits of both operands
 // (v_mfma_f32_32x32x16_bf16, fp32 accumulation); false: v_mfma_f32_32x32x2_f32.
 void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st, bool split_bf16 = false);
+// Small systems (about one 64-row tile per CU or less): the six products of the MLP as ONE launch.  A workgroup takes a
+// row tile through all layers in order — every layer of a tile reads only what the same workgroup wrote for the layer
+// before (activations go through global memory, L2-hot) — which removes five launch/drain gaps and the per-launch
+// prologues that dominate when a launch is ~20 us.  layers[l * nprob + p]: problem p (species bucket) of layer l, all
+// with the same `rows`; epi[l]: its epilogue.  batch must be 1 (one ensemble member).  `plan` caches the device copy.
+struct ChainPlan {
+  void* d_desc = nullptr;      // device: GemmArgs[nlayers * nprob], then int epi[nlayers], int tile_start[nprob + 1]
+  size_t bytes = 0;
+  std::vector<unsigned char> host;
+};
+void launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st);
+void free_chain_plan(ChainPlan& p);
+int mlp_chain_slots();   // workgroups the chain kernel can keep resident (2 per CU)
+
 // dst[kb][N][3][16] bf16 planes of src[N][ld] (first K columns), kb = ceil(K/16); batch matrices src + i*s_src -> dst + i*N*kb*48
 void launch_split_bf16x3(const float* src, int batch, long long s_src, int N, int K, int ld, unsigned short* dst, hipStream_t st);
 inline size_t split_bf16x3_elems(int N, int K) { return (size_t)N * ((K + 15) / 16) * 48; }

@@ -18,6 +18,8 @@
 // B, which leaves the dot products unchanged.  The next slab's global loads are issued before the current slab's
 // MFMAs (register prefetch).  MFMA C layout (guide §3): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "ani_kernels.h"
 
@@ -485,6 +487,171 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
 #pragma unroll
   for (int rt = 0; rt < RT; rt++)
     gemm_epilogue<R, WN, EPI>(g, acc[rt], reinterpret_cast<float*>(lds4), b, n0, row0, t0, tcnt, wm * RT + rt, wn, lr, lh);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Chained MLP for small systems: one workgroup carries a 64-row tile through all the layers (see ani_kernels.h).
+// The tile loop of a layer is the one of gemm_grouped_x3<2, *, 1, 1>.
+// ---------------------------------------------------------------------------------------------------------------
+// WM = 2: 64-row tiles, 2x2 waves;  WM = 1: 32-row tiles, 1x4 waves (twice the workgroups when even 64-row tiles leave CUs idle)
+template <int WM>
+__global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restrict__ layers, const int* __restrict__ epi,
+                                                        const int* __restrict__ tile_start, int nlayers, int nprob) {
+  constexpr int WN = 4 / WM, R = 32 * WM, NTW = 8 / WN, ROW = 112;
+  __shared__ uint4 lds4[(R + 256) * ROW / 16];
+  unsigned char* As = reinterpret_cast<unsigned char*>(lds4);
+  unsigned char* Bs = As + R * ROW;
+  int pi = 0;
+  while (pi + 1 < nprob && (int)blockIdx.x >= tile_start[pi + 1]) pi++;
+  const int tile_m = blockIdx.x - tile_start[pi];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ar = tid >> 2, ak = (tid & 3) * 4;
+
+  for (int l = 0; l < nlayers; l++) {
+    const GemmArgs g = layers[l * nprob + pi];
+    const int e = epi[l];
+    const int row0 = g.row0 + tile_m * R;
+    const int K = g.K, N = g.N;
+    const float* __restrict__ A = g.A + (long long)row0 * g.lda;
+    const float* __restrict__ Am = g.Amask ? g.Amask + (long long)row0 * g.lda : nullptr;
+    const uint4* __restrict__ B3 = reinterpret_cast<const uint4*>(g.Bt3);
+    const int nkt = g.kb3;
+    for (int n0 = 0; n0 < N; n0 += 256) {
+      const int ntiles = min(8, (N - n0 + 31) >> 5);
+      const int per = (ntiles + WN - 1) / WN;
+      const int t0 = wn * per;
+      const int tcnt = max(0, min(per, ntiles - t0));
+      const int brows = min(32 * ntiles, N - n0);
+      f32x16 acc[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+      float4 pa, pan, pm, pmn;
+      uint4 pb[6];
+      auto gloadA = [&](int kb, float4& dst, float4& dstm) {
+        const int kc = kb * 16 + ak;
+        const bool in = kc < K;
+        const bool in2 = in && ar < R;
+        dst = in2 ? *reinterpret_cast<const float4*>(A + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
+        if (Am) dstm = in2 ? *reinterpret_cast<const float4*>(Am + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
+      };
+      auto gloadB = [&](int kb) {
+        const uint4* src = B3 + ((long long)kb * N + n0) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const int c = tid + 256 * i;
+          pb[i] = (kb < nkt && c < 6 * brows) ? src[c] : make_uint4(0, 0, 0, 0);
+        }
+      };
+      gloadA(0, pa, pm);
+      gloadB(0);
+      if (nkt > 1) gloadA(1, pan, pmn);
+      for (int kt = 0; kt < nkt; kt++) {
+        __syncthreads();
+        if (ar < R) {
+          float4 av = pa;
+          if (Am) {
+            av.x *= dcelu_from_h(pm.x, g.inv_alpha); av.y *= dcelu_from_h(pm.y, g.inv_alpha);
+            av.z *= dcelu_from_h(pm.z, g.inv_alpha); av.w *= dcelu_from_h(pm.w, g.inv_alpha);
+          }
+          unsigned h[4], m[4], lo[4];
+          split3(av.x, h[0], m[0], lo[0]); split3(av.y, h[1], m[1], lo[1]);
+          split3(av.z, h[2], m[2], lo[2]); split3(av.w, h[3], m[3], lo[3]);
+          unsigned char* dst = As + ar * ROW + ak * 2;
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+          *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const int c = tid + 256 * i;
+          const int r = c / 6, q = c - 6 * r;
+          if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + q * 16) = pb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) gloadB(kt + 1);
+        pa = pan; pm = pmn;
+        if (kt + 2 < nkt) gloadA(kt + 2, pan, pmn);
+        const unsigned char* ap = As + (32 * wm + lr) * ROW + lh * 16;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
+        const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 64));
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) {
+          if (nt < tcnt) {
+            const unsigned char* bp = Bs + (32 * (t0 + nt) + lr) * ROW + lh * 16;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
+            const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 64));
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      float* ldsf = reinterpret_cast<float*>(lds4);
+      if (e == EPI_CELU) gemm_epilogue<R, WN, EPI_CELU>(g, acc, ldsf, 0, n0, row0, t0, tcnt, wm, wn, lr, lh);
+      else if (e == EPI_LAST) gemm_epilogue<R, WN, EPI_LAST>(g, acc, ldsf, 0, n0, row0, t0, tcnt, wm, wn, lr, lh);
+      else gemm_epilogue<R, WN, EPI_PLAIN>(g, acc, ldsf, 0, n0, row0, t0, tcnt, wm, wn, lr, lh);
+    }
+    // the next layer of this tile reads what this workgroup just stored: the barrier carries the workgroup-scope
+    // release/acquire (stores complete, same CU, same L1)
+    __syncthreads();
+  }
+}
+
+int mlp_chain_slots() {
+  static const int n = [] {
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    return 2 * (v > 0 ? v : 256);
+  }();
+  return n;
+}
+
+void free_chain_plan(ChainPlan& p) {
+  if (p.d_desc) (void)hipFree(p.d_desc);
+  p.d_desc = nullptr; p.bytes = 0; p.host.clear();
+}
+
+void launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st) {
+  std::vector<int> tile_start(nprob + 1, 0);
+  int t64 = 0;
+  for (int i = 0; i < nprob; i++) t64 += layers[i].rows / 64;
+  const int R = (2 * t64 <= mlp_chain_slots()) ? 32 : 64;   // enough slots for twice the workgroups: halve the tiles
+  for (int i = 0; i < nprob; i++) tile_start[i + 1] = tile_start[i] + layers[i].rows / R;
+  const int total = tile_start[nprob];
+  if (total <= 0) return;
+  const size_t b0 = sizeof(GemmArgs) * (size_t)nlayers * nprob, b1 = sizeof(int) * (size_t)nlayers, b2 = sizeof(int) * (size_t)(nprob + 1);
+  std::vector<unsigned char> host(b0 + b1 + b2);
+  memcpy(host.data(), layers, b0);
+  memcpy(host.data() + b0, epi, b1);
+  memcpy(host.data() + b0 + b1, tile_start.data(), b2);
+  if (host != plan->host) {   // descriptors change only with the list epoch / options
+    if (plan->bytes < host.size()) {
+      if (plan->d_desc) (void)hipFree(plan->d_desc);
+      plan->d_desc = nullptr;
+      if (hipMalloc(&plan->d_desc, host.size()) != hipSuccess) { plan->bytes = 0; return; }
+      plan->bytes = host.size();
+    }
+    plan->host = host;
+    (void)hipMemcpyAsync(plan->d_desc, plan->host.data(), host.size(), hipMemcpyHostToDevice, st);
+  }
+  const unsigned char* d = reinterpret_cast<const unsigned char*>(plan->d_desc);
+  if (R == 32)
+    hipLaunchKernelGGL(mlp_chain_x3<1>, dim3(total), dim3(256), 0, st, reinterpret_cast<const GemmArgs*>(d),
+                       reinterpret_cast<const int*>(d + b0), reinterpret_cast<const int*>(d + b0 + b1), nlayers, nprob);
+  else
+    hipLaunchKernelGGL(mlp_chain_x3<2>, dim3(total), dim3(256), 0, st, reinterpret_cast<const GemmArgs*>(d),
+                       reinterpret_cast<const int*>(d + b0), reinterpret_cast<const int*>(d + b0 + b1), nlayers, nprob);
 }
 
 // weights -> blocked bf16 planes

@@ -202,3 +202,21 @@ def test_repulsion_term_rank_invariance_and_oracle(model_cache, hip):
     base = hip.ANI(p0, 0)
     assert abs(base.compute(one, ago=0)["energy"] - ref["energy"]) > 1.0
     base.close()
+
+
+def test_chained_mlp_launch_equals_per_layer_launches(model_cache, hip):
+    """Small single-member systems run the six MLP products as one chained launch (a workgroup carries its row tile through
+    all layers); option mlp_chain = 0 forces the per-layer launches.  Same arithmetic up to the summation order over k
+    (the per-layer kernel rotates its K start per workgroup) and the order of the force atomics: agreement far inside the
+    tolerance.  Sizes below and above the switch from 32- to 64-row tiles, water (pruned AEV) and a 7-species box."""
+    p = model_cache("ani2x", 1, 2024)
+    for inp in (hx.decompose(hx.water_box(3000, seed=3)), hx.decompose(hx.water_box(24000, seed=4)),
+                hx.decompose(hx.random_box(1200, 7, 26.0, seed=6))):
+        ani = hip.ANI(p, 0)
+        a = ani.compute(inp, ago=0)
+        ani.set_option("mlp_chain", 0)
+        b = ani.compute(inp, ago=0)
+        assert np.abs(a["force"] - b["force"]).max() < 0.1 * F_TOL
+        assert abs(a["energy"] - b["energy"]) < 1e-3 * max(1.0, inp.nlocal / 1000.0)
+        assert np.abs(a["eatom"] - b["eatom"]).max() < 1e-4
+        ani.close()
