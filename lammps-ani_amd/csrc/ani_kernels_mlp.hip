@@ -498,9 +498,11 @@ template <int WM>
 __global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restrict__ layers, const int* __restrict__ epi,
                                                         const int* __restrict__ tile_start, int nlayers, int nprob) {
   constexpr int WN = 4 / WM, R = 32 * WM, NTW = 8 / WN, ROW = 112;
-  __shared__ uint4 lds4[(R + 256) * ROW / 16];
-  unsigned char* As = reinterpret_cast<unsigned char*>(lds4);
-  unsigned char* Bs = As + R * ROW;
+  // two LDS stages: slab k+1 is written while slab k is multiplied and slab k+2 is in flight in registers -- one barrier
+  // per slab, and every load has a whole slab to arrive.  (At most two of these workgroups share a CU.)
+  constexpr int STAGE = (R + 256) * ROW;
+  __shared__ uint4 lds4[2 * STAGE / 16];
+  unsigned char* lds = reinterpret_cast<unsigned char*>(lds4);
   int pi = 0;
   while (pi + 1 < nprob && (int)blockIdx.x >= tile_start[pi + 1]) pi++;
   const int tile_m = blockIdx.x - tile_start[pi];
@@ -530,16 +532,13 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restric
       for (int nt = 0; nt < NTW; nt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
-      float4 pa, pan, pm, pmn;
+      float4 pa, pm;
       uint4 pb[6];
-      auto gloadA = [&](int kb, float4& dst, float4& dstm) {
+      auto gload = [&](int kb) {
         const int kc = kb * 16 + ak;
-        const bool in = kc < K;
-        const bool in2 = in && ar < R;
-        dst = in2 ? *reinterpret_cast<const float4*>(A + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
-        if (Am) dstm = in2 ? *reinterpret_cast<const float4*>(Am + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
-      };
-      auto gloadB = [&](int kb) {
+        const bool in = kc < K && ar < R;
+        pa = in ? *reinterpret_cast<const float4*>(A + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
+        if (Am) pm = in ? *reinterpret_cast<const float4*>(Am + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
         const uint4* src = B3 + ((long long)kb * N + n0) * 6;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -547,11 +546,9 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restric
           pb[i] = (kb < nkt && c < 6 * brows) ? src[c] : make_uint4(0, 0, 0, 0);
         }
       };
-      gloadA(0, pa, pm);
-      gloadB(0);
-      if (nkt > 1) gloadA(1, pan, pmn);
-      for (int kt = 0; kt < nkt; kt++) {
-        __syncthreads();
+      auto stage_write = [&](int st) {
+        unsigned char* As = lds + st * STAGE;
+        unsigned char* Bs = As + R * ROW;
         if (ar < R) {
           float4 av = pa;
           if (Am) {
@@ -572,10 +569,17 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restric
           const int r = c / 6, q = c - 6 * r;
           if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + q * 16) = pb[i];
         }
-        __syncthreads();
-        if (kt + 1 < nkt) gloadB(kt + 1);
-        pa = pan; pm = pmn;
-        if (kt + 2 < nkt) gloadA(kt + 2, pan, pmn);
+      };
+      gload(0);
+      stage_write(0);
+      if (nkt > 1) gload(1);
+      __syncthreads();
+      for (int kt = 0; kt < nkt; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) stage_write(cur ^ 1);
+        if (kt + 2 < nkt) gload(kt + 2);
+        const unsigned char* As = lds + cur * STAGE;
+        const unsigned char* Bs = As + R * ROW;
         const unsigned char* ap = As + (32 * wm + lr) * ROW + lh * 16;
         const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
         const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32));
@@ -595,16 +599,16 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restric
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
           }
         }
+        __syncthreads();
       }
-      __syncthreads();
       float* ldsf = reinterpret_cast<float*>(lds4);
       if (e == EPI_CELU) gemm_epilogue<R, WN, EPI_CELU>(g, acc, ldsf, 0, n0, row0, t0, tcnt, wm, wn, lr, lh);
       else if (e == EPI_LAST) gemm_epilogue<R, WN, EPI_LAST>(g, acc, ldsf, 0, n0, row0, t0, tcnt, wm, wn, lr, lh);
       else gemm_epilogue<R, WN, EPI_PLAIN>(g, acc, ldsf, 0, n0, row0, t0, tcnt, wm, wn, lr, lh);
+      __syncthreads();   // the staging memory is reused (and, for EPI_LAST, was scratch of the epilogue)
     }
-    // the next layer of this tile reads what this workgroup just stored: the barrier carries the workgroup-scope
+    // the next layer of this tile reads what this workgroup just stored: the barrier above carries the workgroup-scope
     // release/acquire (stores complete, same CU, same L1)
-    __syncthreads();
   }
 }
 
