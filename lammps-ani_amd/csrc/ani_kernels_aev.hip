@@ -456,8 +456,7 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
         const float dr = L.rr[t] - shf;
         acc = fmaf(fexp2(c * dr * dr), L.rfc[t], acc);
       }
-      acc += __shfl_xor(acc, 16);
-      acc += __shfl_xor(acc, 32);
+      acc = xor_sum<32>(xor_sum<16>(acc));   // row / half-wave swaps, no LDS round trip
       if (q == 0) L.row[s * NR + k] = 0.25f * acc;
     }
   }
@@ -479,8 +478,9 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
 #pragma unroll
       for (int z = 0; z < NZ; z++) {
         float v = acc[z];
-#pragma unroll
-        for (int off = NA; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        if constexpr (NA <= 4) v = xor_sum<4>(v);
+        if constexpr (NA <= 8) v = xor_sum<8>(v);
+        v = xor_sum<32>(xor_sum<16>(v));
         acc[z] = v;
       }
       if (lq == 0) {
@@ -781,12 +781,9 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     wv[3] += gy * dx; wv[4] += gy * dy; wv[5] += gy * dz;
     wv[6] += gz * dx; wv[7] += gz * dy; wv[8] += gz * dz;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    fx += __shfl_xor(fx, off);
-    fy += __shfl_xor(fy, off);
-    fz += __shfl_xor(fz, off);
-  }
+  fx = xor_sum<32>(xor_sum<16>(xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(fx))))));
+  fy = xor_sum<32>(xor_sum<16>(xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(fy))))));
+  fz = xor_sum<32>(xor_sum<16>(xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(fz))))));
   const int i = info.x;
 #ifndef ABL_NO_GATOM
   // neighbour forces, lane = (list slot, component): global float atomics execute at the memory side as 64-byte
