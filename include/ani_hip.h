@@ -156,7 +156,8 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *       one fp32 rounding; 2.7x the matrix rate of the fp32-input instruction).  0 uses v_mfma_f32_32x32x2_f32.
  *       Takes effect at the next call.
  *   "mlp_chain" (default 1): with one ensemble member and few row tiles (small systems) the six MLP products run as one
- *       chained launch instead of six grouped ones.  Takes effect at the next call.
+ *       chained launch instead of six grouped ones; 2 = at any size (measurement knob), 0 = never.  Takes effect at the
+ *       next call.
  *   "full_radial_capacity" (default 0): with the radial screen at Rcr (use_cuaev = 1) the kernels reserve LDS for 3/4
  *       of the longest neighbour list (>= 128 entries) per centre -- a uniform 7.1 A list holds 37 % of its entries
  *       inside 5.1 A -- instead of all of it; a centre that needs more raises ANI_ERR_CAPACITY.  1 reserves the full

@@ -77,7 +77,7 @@ struct ani_handle {
   SpeciesMap cmap{};  // species -> index among the species present
   int active_mask = -1;
   bool prune = true;  // ani_set_option("prune_absent_species")
-  bool mlp_chain = true;   // ani_set_option("mlp_chain"): one chained launch for the MLP of small systems
+  int mlp_chain = 1;   // ani_set_option("mlp_chain"): 1 = one chained launch for the MLP of small systems, 2 = at any size, 0 = never
   ChainPlan chain_plan;
   bool mlp_split = true;  // ani_set_option("mlp_split_bf16"): six bf16 MFMA products per fp32 product instead of fp32-input MFMA
   std::vector<int> colmap;  // ap_run column -> ap column
@@ -491,7 +491,7 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
   const int np = (int)layer_probs[0].size();
   int tiles = 0;
   for (const GemmArgs& g : layer_probs[0]) tiles += g.rows / 64;
-  bool chain = h->mlp_chain && h->mlp_split && M == 1 && np > 0 && tiles <= mlp_chain_slots();
+  bool chain = h->mlp_chain && h->mlp_split && M == 1 && np > 0 && (h->mlp_chain > 1 || tiles <= mlp_chain_slots());
   for (const auto& lp : layer_probs) chain = chain && (int)lp.size() == np;
   if (chain) {
     std::vector<GemmArgs> flat;
@@ -973,7 +973,7 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
     return ANI_OK;
   }
   if (strcmp(name, "mlp_chain") == 0) {
-    h->mlp_chain = value != 0;
+    h->mlp_chain = value;
     return ANI_OK;
   }
   if (strcmp(name, "mlp_split_bf16") == 0) {
