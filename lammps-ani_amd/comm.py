@@ -25,6 +25,7 @@ class GhostExchange:
         self.device, self.dtype = device, dtype
         # rehearsal mode: gloo cannot move device tensors, so messages are staged through the host (only used to run
         # the multi-rank path on a single GPU; the real path is backend nccl = RCCL with device buffers)
+        self.identity_perm = False
         self.host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda")
         order = np.argsort(inp.owner_rank, kind="stable")
         self.ghost_perm = torch.as_tensor(order.astype(np.int64), device=device)          # ghosts sorted by owner
@@ -53,6 +54,7 @@ class GhostExchange:
         assert self.world == 1
         self.nghost = int(owner_idx.numel())
         self.ghost_perm = torch.arange(self.nghost, device=self.device)
+        self.identity_perm = True   # ghosts already in message order: the permutation gathers/scatters are skipped
         self.recv_idx = owner_idx
         self.shift = shift.to(self.dtype)
         self.send_splits = self.recv_splits = [self.nghost]
@@ -71,6 +73,9 @@ class GhostExchange:
         """f: [ntotal,3]; adds every ghost's force into its owner's row (on whichever rank that is)."""
         if self.nghost == 0 and self.recv_idx.numel() == 0:
             return
+        if self.world == 1 and self.identity_perm:
+            f[: self.nlocal].index_add_(0, self.recv_idx, f[self.nlocal:])
+            return
         torch.index_select(f[self.nlocal:], 0, self.ghost_perm, out=self._send)
         if self.world > 1:
             self._a2a(self._recv, self._send, self.recv_splits, self.send_splits)
@@ -83,11 +88,14 @@ class GhostExchange:
         if self.nghost == 0 and self.recv_idx.numel() == 0:
             return
         torch.index_select(x[: self.nlocal], 0, self.recv_idx, out=self._recv)
+        if self.world == 1 and self.identity_perm:
+            torch.add(self._recv, self.shift, out=x[self.nlocal:])
+            return
         if self.world > 1:
             self._a2a(self._send, self._recv, self.send_splits, self.recv_splits)
+            x[self.nlocal:].index_copy_(0, self.ghost_perm, self._send + self.shift)
         else:
-            self._send.copy_(self._recv)
-        x[self.nlocal:].index_copy_(0, self.ghost_perm, self._send + self.shift)
+            x[self.nlocal:].index_copy_(0, self.ghost_perm, self._recv + self.shift)
 
 
 def grid_for(nranks: int):

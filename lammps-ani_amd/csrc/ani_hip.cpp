@@ -320,7 +320,7 @@ int rebuild(ani_handle* h, hipStream_t st) {
   const int nlocal = h->nlocal;
   const int nrows_cap = round_up(nlocal, kRowTile) + m.S * kRowTile;
   HIP_TRY(h, h->nbr_off.reserve((size_t)nlocal + 1));
-  HIP_TRY(h, h->row_of_centre.reserve((size_t)2 * nlocal + 2));
+  HIP_TRY(h, h->row_of_centre.reserve(prepare_scratch_ints(nlocal)));
   HIP_TRY(h, h->centre_of_row.reserve(nrows_cap));
   HIP_TRY(h, h->row_info.reserve(nrows_cap));
   HIP_TRY(h, h->bucket_info.reserve(kBucketInfoInts));

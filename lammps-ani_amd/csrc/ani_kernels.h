@@ -75,11 +75,12 @@ void launch_pack(const double* d_x, const int* d_species, int ntotal, const Spec
 // rebuild-time preparation: neighbour offsets, species buckets.  All outputs device arrays.
 struct PrepOut {
   int* nbr_off;         // [nlocal+1] exclusive scan of numneigh
-  int* row_of_centre;   // [nlocal]
+  int* row_of_centre;   // [prepare_scratch_ints(nlocal)]: [nlocal] rows, then scratch
   int* centre_of_row;   // [nrows_cap] (-1 = padding)
   int4* row_info;       // [nrows_cap] per AEV row: {i, list begin, list length, ii}; i = -1 for padding rows
   int* bucket_info;     // [kBucketInfoInts]: count[s], row_start[s], nrows, bad_species flag, max numneigh, species-present mask
 };
+size_t prepare_scratch_ints(int nlocal);   // size of PrepOut::row_of_centre (rows + scratch of the two kernels)
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
                     const PrepOut& o, hipStream_t st);
 

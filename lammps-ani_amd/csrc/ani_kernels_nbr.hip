@@ -7,9 +7,8 @@
 //
 // Layout: atoms are counting-sorted by cell (`order`, ascending atom index inside a cell, so the list is
 // deterministic) and their positions copied in that order (`xs`), which makes the three x-adjacent cells of a
-// (y,z) column one contiguous range.  One thread per atom in sorted order: neighbouring lanes walk the same ranges,
-// so the loads are broadcasts out of L1/L2.  Two passes (count, fill) around one scan; the list is HBM-bound
-// integer work (4 B per pair written once).
+// (y,z) column one contiguous range.  Sixteen lanes per atom in sorted order walk each range together.  Two passes
+// (count, fill) around one scan; the list is HBM-bound integer work (4 B per pair written once).
 #include "ani_kernels.h"
 #include "ani_scan.h"
 
@@ -41,16 +40,52 @@ __global__ void nbr_bin_count_kernel(const double* __restrict__ x, int ntotal, N
 // out[0..n] = exclusive scan of in[0..n), single block
 __global__ __launch_bounds__(1024) void nbr_scan_kernel(const int* __restrict__ in, int* __restrict__ out, int n) {
   __shared__ int wave_sums[16];
-  int carry = 0;
-  for (int base = 0; base < n; base += blockDim.x) {
-    const int i = base + threadIdx.x;
-    const int v = i < n ? in[i] : 0;
-    int total;
-    const int ex = block_exclusive_scan(v, total, wave_sums);
-    if (i < n) out[i] = carry + ex;
-    carry += total;
+  const int total = block_scan_rounds<8>(n, wave_sums, [&](int i) { return in[i]; }, [&](int i, int ex, int) { out[i] = ex; });
+  if (threadIdx.x == 0) out[n] = total;
+}
+
+// the same scan over many blocks, for arrays with one entry per atom: chunk-relative prefixes and chunk totals, then
+// the totals of the chunks before are added (one block scanning 100 000 entries round after round took ~0.1 ms)
+constexpr int kScanVpt = 4, kScanChunk = 1024 * kScanVpt;
+
+__global__ __launch_bounds__(1024) void scan_chunk_kernel(const int* __restrict__ in, int* __restrict__ out, int n,
+                                                           int* __restrict__ chunk_tot) {
+  __shared__ int wave_sums[16];
+  const int i0 = blockIdx.x * kScanChunk + threadIdx.x * kScanVpt;
+  int v[kScanVpt], s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanVpt; k++) {
+    v[k] = i0 + k < n ? in[i0 + k] : 0;
+    s += v[k];
   }
-  if (threadIdx.x == 0) out[n] = carry;
+  int total;
+  int ex = block_exclusive_scan(s, total, wave_sums);
+#pragma unroll
+  for (int k = 0; k < kScanVpt; k++) {
+    if (i0 + k < n) out[i0 + k] = ex;
+    ex += v[k];
+  }
+  if (threadIdx.x == 0) chunk_tot[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_add_kernel(int* __restrict__ out, int n, const int* __restrict__ chunk_tot, int nchunks) {
+  __shared__ int before;
+  const int chunk = (blockIdx.x * blockDim.x) / kScanChunk;   // kScanChunk is a multiple of the block size
+  if (threadIdx.x < 64) {
+    int acc = 0;
+    for (int c = threadIdx.x; c < chunk; c += 64) acc += chunk_tot[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (threadIdx.x == 0) before = acc;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += before;
+  else if (i == n) {
+    int acc = 0;
+    for (int c = 0; c < nchunks; c++) acc += chunk_tot[c];
+    out[n] = acc;
+  }
 }
 
 __global__ void nbr_bin_fill_kernel(const int* __restrict__ cell_id, const int* __restrict__ cell_start,
@@ -61,17 +96,39 @@ __global__ void nbr_bin_fill_kernel(const int* __restrict__ cell_id, const int* 
   order[cell_start[c] + atomicAdd(&cursor[c], 1)] = a;
 }
 
-// ascending atom index inside every cell (the atomics above fill in arbitrary order)
-__global__ void nbr_bin_sort_kernel(const int* __restrict__ cell_start, int* __restrict__ order, int ncell) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// ascending atom index inside every cell (the atomics above fill in arbitrary order).  One wave per cell: every lane
+// holds up to four entries and ranks them by counting the smaller ones (atom indices are distinct), then writes each
+// entry to its rank -- all reads of the cell precede the writes in the wave's program order, so this is in place.
+__global__ __launch_bounds__(256) void nbr_bin_sort_kernel(const int* __restrict__ cell_start, int* __restrict__ order, int ncell) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (c >= ncell) return;
-  const int beg = cell_start[c], end = cell_start[c + 1];
-  for (int p = beg + 1; p < end; p++) {
-    const int v = order[p];
-    int q = p - 1;
-    while (q >= beg && order[q] > v) { order[q + 1] = order[q]; q--; }
-    order[q + 1] = v;
+  const int beg = cell_start[c], n = cell_start[c + 1] - beg;
+  if (n <= 1) return;
+  if (n > 256) {   // denser than any physical system at these cell sizes: serial insertion sort
+    if (lane == 0)
+      for (int p = beg + 1; p < beg + n; p++) {
+        const int v = order[p];
+        int q = p - 1;
+        while (q >= beg && order[q] > v) { order[q + 1] = order[q]; q--; }
+        order[q + 1] = v;
+      }
+    return;
   }
+  int v[4], rk[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int idx = lane + 64 * k;
+    v[k] = idx < n ? order[beg + idx] : 0x7fffffff;
+    rk[k] = 0;
+  }
+  for (int q = 0; q < n; q++) {
+    const int e = order[beg + q];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rk[k] += e < v[k] ? 1 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (lane + 64 * k < n) order[beg + rk[k]] = v[k];
 }
 
 __global__ void nbr_gather_kernel(const double* __restrict__ x, const int* __restrict__ order, int ntotal,
@@ -82,12 +139,21 @@ __global__ void nbr_gather_kernel(const double* __restrict__ x, const int* __res
   xs[3 * p] = x[3 * a]; xs[3 * p + 1] = x[3 * a + 1]; xs[3 * p + 2] = x[3 * a + 2];
 }
 
+// kSearchLanes lanes per atom: the candidates of a cell range are taken kSearchLanes at a time (contiguous positions:
+// coalesced), hits are placed by a ballot over the group -- the order of a list is the serial order (cell ranges, then
+// sorted position), whatever the lane count.  One lane per atom left the chip latency-bound (2 waves per SIMD, a
+// dependent L2 load per candidate).
+constexpr int kSearchLanes = 16;
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void nbr_search_kernel(const double* __restrict__ xs, const int* __restrict__ order,
                                                           const int* __restrict__ cell_start, NbrGrid g, int nlocal,
                                                           int ntotal, double cut2, int* __restrict__ numneigh,
                                                           const int* __restrict__ nbr_off, int* __restrict__ jlist) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int L = kSearchLanes;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = (int)(t / L), l = threadIdx.x & (L - 1);
+  const int grp_shift = (threadIdx.x & 63) & ~(L - 1);   // where this group's bits sit in the wave ballot
   if (p >= ntotal) return;
   const int i = order[p];
   if (i >= nlocal) return;  // ghosts are neighbours only
@@ -105,17 +171,21 @@ __global__ __launch_bounds__(256) void nbr_search_kernel(const double* __restric
       if (y < 0 || y >= g.nc[1]) continue;
       const int rowc = (z * g.nc[1] + y) * g.nc[0];
       const int beg = cell_start[rowc + x0], end = cell_start[rowc + x1 + 1];
-      for (int q = beg; q < end; q++) {
-        const double ddx = xs[3 * q] - xi, ddy = xs[3 * q + 1] - yi, ddz = xs[3 * q + 2] - zi;
-        const double r2 = ddx * ddx + ddy * ddy + ddz * ddz;
-        if (r2 <= cut2 && q != p) {  // rsq <= cutneighsq, as LAMMPS' npair full/bin
-          if (FILL) out[n] = order[q];
-          n++;
+      for (int q0 = beg; q0 < end; q0 += L) {
+        const int q = q0 + l;
+        bool hit = false;
+        if (q < end) {
+          const double ddx = xs[3 * q] - xi, ddy = xs[3 * q + 1] - yi, ddz = xs[3 * q + 2] - zi;
+          const double r2 = ddx * ddx + ddy * ddy + ddz * ddz;
+          hit = r2 <= cut2 && q != p;  // rsq <= cutneighsq, as LAMMPS' npair full/bin
         }
+        const unsigned bits = (unsigned)(__ballot(hit) >> grp_shift) & ((1u << L) - 1u);
+        if (FILL && hit) out[n + __popc(bits & ((1u << l) - 1u))] = order[q];
+        n += __popc(bits);
       }
     }
   }
-  if (!FILL) numneigh[i] = n;
+  if (!FILL && l == 0) numneigh[i] = n;
 }
 
 __global__ void iota_kernel(int* __restrict__ out, int n) {
@@ -136,22 +206,26 @@ void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrSc
   hipLaunchKernelGGL(nbr_bin_count_kernel, grid, block, 0, st, d_x, ntotal, g, s.cell_id, s.cell_count);
   hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, s.cell_count, s.cell_start, g.ncell);
   hipLaunchKernelGGL(nbr_bin_fill_kernel, grid, block, 0, st, s.cell_id, s.cell_start, s.cursor, s.order, ntotal);
-  hipLaunchKernelGGL(nbr_bin_sort_kernel, dim3((g.ncell + 255) / 256), block, 0, st, s.cell_start, s.order, g.ncell);
+  hipLaunchKernelGGL(nbr_bin_sort_kernel, dim3((g.ncell + 3) / 4), block, 0, st, s.cell_start, s.order, g.ncell);
   hipLaunchKernelGGL(nbr_gather_kernel, grid, block, 0, st, d_x, s.order, ntotal, s.xs);
 }
 
 void launch_nbr_count(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int* d_numneigh,
                       int* d_nbr_off, hipStream_t st) {
   if (nlocal > 0 && ntotal > 0)
-    hipLaunchKernelGGL(nbr_search_kernel<false>, dim3((ntotal + 255) / 256), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
+    hipLaunchKernelGGL(nbr_search_kernel<false>, dim3((unsigned)(((long long)ntotal * kSearchLanes + 255) / 256)), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
                        nlocal, ntotal, cutneigh * cutneigh, d_numneigh, nullptr, nullptr);
-  hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, d_numneigh, d_nbr_off, nlocal);
+  // cell_id is free once the atoms are binned: scratch for the chunk totals (nlocal / 4096 + 1 <= ntotal entries)
+  const int nchunks = nlocal / kScanChunk + 1;
+  if (nchunks > ntotal) { hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, d_numneigh, d_nbr_off, nlocal); return; }
+  hipLaunchKernelGGL(scan_chunk_kernel, dim3(nchunks), dim3(1024), 0, st, d_numneigh, d_nbr_off, nlocal, s.cell_id);
+  hipLaunchKernelGGL(scan_add_kernel, dim3((nlocal + 256) / 256), dim3(256), 0, st, d_nbr_off, nlocal, s.cell_id, nchunks);
 }
 
 void launch_nbr_fill(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, const int* d_nbr_off,
                      int* d_jlist, int* d_ilist, hipStream_t st) {
   if (nlocal <= 0 || ntotal <= 0) return;
-  hipLaunchKernelGGL(nbr_search_kernel<true>, dim3((ntotal + 255) / 256), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
+  hipLaunchKernelGGL(nbr_search_kernel<true>, dim3((unsigned)(((long long)ntotal * kSearchLanes + 255) / 256)), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
                      nlocal, ntotal, cutneigh * cutneigh, nullptr, d_nbr_off, d_jlist);
   hipLaunchKernelGGL(iota_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, st, d_ilist, nlocal);
 }

@@ -28,4 +28,30 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int& total, int* wave
   return base + incl - v;
 }
 
+// exclusive scan of n values by ONE block, VPT consecutive values per thread and round (a 1024-thread block covers
+// 8192 values per round at VPT = 8: two barriers per 8192 values instead of per 1024).  load(i) gives value i,
+// store(i, exclusive_prefix, value) receives the result; returns the total.
+template <int VPT, typename Load, typename Store>
+__device__ __forceinline__ int block_scan_rounds(int n, int* wave_sums, Load load, Store store) {
+  int carry = 0;
+  for (int base = 0; base < n; base += blockDim.x * VPT) {
+    const int i0 = base + threadIdx.x * VPT;
+    int v[VPT], s = 0;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      v[k] = (i0 + k < n) ? load(i0 + k) : 0;
+      s += v[k];
+    }
+    int total;
+    int ex = carry + block_exclusive_scan(s, total, wave_sums);
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      if (i0 + k < n) store(i0 + k, ex, v[k]);
+      ex += v[k];
+    }
+    carry += total;
+  }
+  return carry;
+}
+
 }  // namespace ani

@@ -52,10 +52,22 @@ class VerletRun:
         if self.reghost:
             self.box_lo = torch.as_tensor(np.asarray(box_lo, dtype=np.float64), device=device)
             assert float(self.box_len.min()) >= self.cutneigh, "box shorter than the neighbour cutoff: images beyond +-1 needed"
+            self._image_combos = torch.tensor([(a, b, c) for a in range(3) for b in range(3) for c in range(3) if (a, b, c) != (1, 1, 1)],
+                                              dtype=torch.long, device=device)
+            self._box_lo_np = np.asarray(box_lo, dtype=np.float64)
+            self._box_len_np = np.asarray(box_len, dtype=np.float64)
         self.x = torch.as_tensor(inp.x, dtype=torch.float64, device=device).contiguous()
         self.species = torch.as_tensor(inp.species.astype(np.int32), device=device)
         m = torch.as_tensor(np.asarray(masses, dtype=np.float64), device=device)[self.species[: self.nlocal].long()]
         self.mass = m[:, None]
+        # per-atom factors of the integrator, expanded once so that each update is ONE fused device kernel
+        self._dtf_over_m = ((0.5 * float(dt) * FTM2V) / self.mass).expand(-1, 3).contiguous()
+        self._lang = None
+        if langevin is not None:
+            T, damp = langevin
+            g1 = (-self.mass / damp / FTM2V).expand(-1, 3).contiguous()
+            g2 = (torch.sqrt(self.mass) * (24.0 * BOLTZ * T / damp / float(dt) / MVV2E) ** 0.5 / FTM2V).expand(-1, 3).contiguous()
+            self._lang = (g1, g2, torch.empty((self.nlocal, 3), dtype=torch.float64, device=device))
         self.v = torch.zeros((self.nlocal, 3), dtype=torch.float64, device=device)
         self.f = torch.zeros((self.ntotal, 3), dtype=torch.float64, device=device)
         self.ev = torch.zeros(10, dtype=torch.float64, device=device)
@@ -88,24 +100,14 @@ class VerletRun:
         xl = self.x[:n]
         xl -= torch.floor((xl - lo) / L) * L
         near_lo, near_hi = xl < lo + cut, xl >= lo + L - cut
-        ones = torch.ones(n, dtype=torch.bool, device=self.device)
-        owners, shifts = [], []
-        for sx in (-1, 0, 1):
-            for sy in (-1, 0, 1):
-                for sz in (-1, 0, 1):
-                    if sx == sy == sz == 0:
-                        continue
-                    mask = ones
-                    for d, s in enumerate((sx, sy, sz)):
-                        if s == 1:
-                            mask = mask & near_lo[:, d]
-                        elif s == -1:
-                            mask = mask & near_hi[:, d]
-                    idx = mask.nonzero().squeeze(1)
-                    owners.append(idx)
-                    sh = torch.tensor([sx, sy, sz], dtype=torch.float64, device=self.device) * L
-                    shifts.append(sh.expand(idx.numel(), 3))
-        owner, shift = torch.cat(owners), torch.cat(shifts)
+        # the 26 image shifts at once: cond[s + 1, atom, d] says whether the atom has an image displaced by s box lengths
+        # along d; one nonzero() (one host sync) lists the (shift, atom) pairs shift-major, atoms ascending
+        cond = torch.stack([near_hi, torch.ones_like(near_lo), near_lo], 0)
+        cb = self._image_combos
+        mask = cond[cb[:, 0], :, 0] & cond[cb[:, 1], :, 1] & cond[cb[:, 2], :, 2]
+        hit = mask.nonzero()
+        owner = hit[:, 1]
+        shift = (cb[hit[:, 0]] - 1).to(torch.float64) * L
         self.ex.reset_single(owner, shift)
         self.ntotal = n + int(owner.numel())
         self.x = torch.cat([xl, xl[owner] + shift]).contiguous()
@@ -123,8 +125,12 @@ class VerletRun:
             raise RuntimeError(f"an atom moved {moved:.2f} A from its set-up position, more than ghost_margin/2 = "
                                f"{0.5 * self.ghost_margin:.2f} A: the fixed ghost shell of this stand-in no longer "
                                "covers the neighbour cutoff (re-decompose, or raise ghost_margin)")
-        lo = (self.x.min(0).values - 0.25).cpu().numpy()
-        hi = (self.x.max(0).values + 0.25).cpu().numpy()
+        if self.reghost:   # owned atoms were just wrapped into the box and the ghosts lie within cutneigh of its faces
+            lo = self._box_lo_np - self.cutneigh - 0.25
+            hi = self._box_lo_np + self._box_len_np + self.cutneigh + 0.25
+        else:
+            lo = (self.x.min(0).values - 0.25).cpu().numpy()
+            hi = (self.x.max(0).values + 0.25).cpu().numpy()
         self.npairs = self.ani.build_list_device(self.ntotal, self.nlocal, self.species.data_ptr(), self.x.data_ptr(),
                                                  self.cutneigh, lo, hi, stream=self._stream)
         self.x_built.copy_(self.x[: self.nlocal])
@@ -136,13 +142,13 @@ class VerletRun:
         self.ani.compute_device(self.ntotal, self.nlocal, None, self.x.data_ptr(), self.npairs, None, None, None, 1,
                                 self.f.data_ptr(), self.ev.data_ptr(), stream=self._stream)
         self.ex.reverse_add(self.f)
-        if self.langevin is not None:
-            # fix langevin (LAMMPS fix_langevin.cpp, uniform random numbers): drag + random force on owned atoms
-            T, damp = self.langevin
-            g1 = -self.mass / damp / FTM2V
-            g2 = torch.sqrt(self.mass) * (24.0 * BOLTZ * T / damp / self.dt / MVV2E) ** 0.5 / FTM2V
-            r = torch.rand((self.nlocal, 3), dtype=torch.float64, device=self.device, generator=self.gen) - 0.5
-            self.f[: self.nlocal] += g1 * self.v + g2 * r
+        if self._lang is not None:
+            # fix langevin (LAMMPS fix_langevin.cpp, uniform random numbers in [-0.5, 0.5)): f += g1 v + g2 r on owned atoms
+            g1, g2, r = self._lang
+            r.uniform_(-0.5, 0.5, generator=self.gen)
+            fl = self.f[: self.nlocal]
+            fl.addcmul_(g1, self.v)
+            fl.addcmul_(g2, r)
 
     def create_velocities(self, T: float):
         """``velocity all create T seed mom yes dist gaussian`` (examples/benchmark/in.lammps:54)."""
@@ -175,10 +181,9 @@ class VerletRun:
         return float(t)
 
     def step(self):
-        dtf = 0.5 * self.dt * FTM2V
-        # fix nve initial_integrate
-        self.v += dtf * self.f[: self.nlocal] / self.mass
-        self.x[: self.nlocal] += self.dt * self.v
+        # fix nve initial_integrate: v += dtf f / m ; x += dt v
+        self.v.addcmul_(self.f[: self.nlocal], self._dtf_over_m)
+        self.x[: self.nlocal].add_(self.v, alpha=self.dt)
         self.step_no += 1
         self.since_build += 1
         # Neighbor::decide + check_distance (every N steps, rebuild if any atom moved more than skin/2)
@@ -193,7 +198,7 @@ class VerletRun:
             self.ex.forward_positions(self.x)
         self._forces()
         # fix nve final_integrate
-        self.v += dtf * self.f[: self.nlocal] / self.mass
+        self.v.addcmul_(self.f[: self.nlocal], self._dtf_over_m)
 
     # ---- thermo ------------------------------------------------------------------------------------------
     def kinetic_energy(self) -> float:
