@@ -127,6 +127,17 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
  */
 int ani_build_list_device(ani_handle* h, int ntotal, int nlocal, const int* d_species, const double* d_x, double cutneigh,
                           const double* lo, const double* hi, int64_t* out_npairs, void* stream);
+
+/*
+ * The same list build for callers that hold species and positions on the HOST (the role of LAMMPS' own neighbour
+ * build for a non-Kokkos run: `pair_style ani ... devlist` of lammps-ani_amd/csrc/pair_ani.cpp requests only an
+ * occasional list from LAMMPS, never builds it, and calls this at re-neighbouring steps instead of flattening and
+ * uploading LAMMPS' host list).  Uploads species[ntotal] (int64, as ani_compute_full takes them) and
+ * coordinates[ntotal*3], builds and installs the list.  Follow with ani_compute_full(..., ago != 0, NULL list
+ * pointers).  Pairs are selected by distance only: no special-bond exclusions (ANI has no topology).
+ */
+int ani_build_list(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates, double cutneigh,
+                   const double* lo, const double* hi, int64_t* out_npairs);
 /* device pointers of the installed list (tests): numneigh[nlocal], its exclusive scan [nlocal+1], jlist[npairs] */
 int ani_debug_list(ani_handle* h, const int** d_numneigh, const int** d_nbr_off, const int** d_jlist);
 

@@ -20,7 +20,7 @@ HARTREE2KCALMOL = 627.5094738898777
 
 EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani_use_num_models", "ani_num_species",
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
-           "ani_compute_full_device", "ani_build_list_device", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times"]
+           "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times"]
 
 
 class AniError(RuntimeError):
@@ -70,6 +70,8 @@ def lib():
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ani_build_list_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
                                             C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+        L.ani_build_list.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                     C.c_void_p, C.POINTER(C.c_int64)]
         L.ani_debug_list.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3
         L.ani_debug_get.argtypes = [C.c_void_p, C.POINTER(DebugView)]
         L.ani_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -151,6 +153,22 @@ class ANI:
         n = C.c_int64()
         self._check(self._lib.ani_build_list_device(self._h, ntotal, nlocal, d_species, d_x, float(cutneigh),
                                                     lo.ctypes.data, hi.ctypes.data, C.byref(n), stream))
+        return n.value
+
+    def build_list(self, species, x, nlocal: int, cutneigh: float, lo=None, hi=None) -> int:
+        """Host-array form (ani_build_list): species[ntotal], x[ntotal,3] with owned atoms first; returns the pair
+        count.  Follow with the host-pointer compute at ago != 0."""
+        species = np.ascontiguousarray(species, dtype=np.int64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if lo is None:   # per column: numpy's axis-0 reduction of an [n,3] array is ~10x slower
+            lo = [x[:, k].min() - 0.25 for k in range(3)]
+        if hi is None:
+            hi = [x[:, k].max() + 0.25 for k in range(3)]
+        lo = np.ascontiguousarray(lo, dtype=np.float64)
+        hi = np.ascontiguousarray(hi, dtype=np.float64)
+        n = C.c_int64()
+        self._check(self._lib.ani_build_list(self._h, x.shape[0], nlocal, species.ctypes.data, x.ctypes.data, float(cutneigh),
+                                             lo.ctypes.data, hi.ctypes.data, C.byref(n)))
         return n.value
 
     def debug_list(self, nlocal: int):

@@ -815,15 +815,13 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
   return run_step(h, d_x, eflag_atom, vflag, d_f, /*accumulate=*/1, d_ev, d_eatom, st);
 }
 
-int ani_build_list_device(ani_handle* h, int ntotal, int nlocal, const int* d_species, const double* d_x, double cutneigh,
-                          const double* lo, const double* hi, int64_t* out_npairs, void* stream) {
-  int rc = check_args(h, ntotal, nlocal, 0, 0);
-  if (rc) return rc;
-  if (!d_species || !d_x || !lo || !hi) { h->err = "null pointer"; return ANI_ERR_ARG; }
-  if (!(cutneigh >= h->model.Rcr)) { h->err = "cutneigh must be at least the model's radial cutoff"; return ANI_ERR_ARG; }
-  if (!h->use_fullnbr) { h->err = "ani_build_list_device builds a full list; the handle was created for half lists"; return ANI_ERR_ARG; }
-  HIP_TRY(h, hipSetDevice(h->device));
-  hipStream_t st = (hipStream_t)stream;
+}  // extern "C"
+
+namespace {
+// the list build proper; d_species may be h->species.p itself (already in place) or a caller's device array
+int build_list(ani_handle* h, int ntotal, int nlocal, const int* d_species, const double* d_x, double cutneigh, const double* lo,
+               const double* hi, int64_t* out_npairs, hipStream_t st) {
+  int rc = 0;
   NbrGrid g;
   long long ncell = 1;
   for (int k = 0; k < 3; k++) {
@@ -849,7 +847,8 @@ int ani_build_list_device(ani_handle* h, int ntotal, int nlocal, const int* d_sp
   HIP_TRY(h, h->numneigh.reserve(nlocal));
   HIP_TRY(h, h->nbr_off.reserve((size_t)nlocal + 1));
   NbrScratch s{h->nb_cell_id.p, h->nb_cell_count.p, h->nb_cell_start.p, h->nb_cursor.p, h->nb_order.p, h->nb_xs.p};
-  HIP_TRY(h, hipMemcpyAsync(h->species.p, d_species, sizeof(int) * (size_t)ntotal, hipMemcpyDeviceToDevice, st));
+  if (d_species != h->species.p)
+    HIP_TRY(h, hipMemcpyAsync(h->species.p, d_species, sizeof(int) * (size_t)ntotal, hipMemcpyDeviceToDevice, st));
   launch_nbr_bin(d_x, ntotal, g, s, st);
   launch_nbr_count(nlocal, ntotal, g, s, cutneigh, h->numneigh.p, h->nbr_off.p, st);
   int total = 0;
@@ -866,6 +865,42 @@ int ani_build_list_device(ani_handle* h, int ntotal, int nlocal, const int* d_sp
   h->have_list = true;
   if (out_npairs) *out_npairs = total;
   return ANI_OK;
+}
+
+int build_list_args(ani_handle* h, int ntotal, int nlocal, const void* species, const void* x, double cutneigh, const double* lo,
+                    const double* hi, const char* who) {
+  int rc = check_args(h, ntotal, nlocal, 0, 0);
+  if (rc) return rc;
+  if (!species || !x || !lo || !hi) { h->err = "null pointer"; return ANI_ERR_ARG; }
+  if (!(cutneigh >= h->model.Rcr)) { h->err = "cutneigh must be at least the model's radial cutoff"; return ANI_ERR_ARG; }
+  if (!h->use_fullnbr) { h->err = std::string(who) + " builds a full list; the handle was created for half lists"; return ANI_ERR_ARG; }
+  return ANI_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ani_build_list_device(ani_handle* h, int ntotal, int nlocal, const int* d_species, const double* d_x, double cutneigh,
+                          const double* lo, const double* hi, int64_t* out_npairs, void* stream) {
+  const int rc = build_list_args(h, ntotal, nlocal, d_species, d_x, cutneigh, lo, hi, "ani_build_list_device");
+  if (rc) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  return build_list(h, ntotal, nlocal, d_species, d_x, cutneigh, lo, hi, out_npairs, (hipStream_t)stream);
+}
+
+int ani_build_list(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates, double cutneigh,
+                   const double* lo, const double* hi, int64_t* out_npairs) {
+  const int rc = build_list_args(h, ntotal, nlocal, species, coordinates, cutneigh, lo, hi, "ani_build_list");
+  if (rc) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t st = h->stream;
+  h->h_species32.resize(ntotal);
+  for (int i = 0; i < ntotal; i++) h->h_species32[i] = (int)species[i];
+  HIP_TRY(h, h->species.reserve(ntotal));
+  HIP_TRY(h, h->x64.reserve((size_t)ntotal * 3));
+  HIP_TRY(h, hipMemcpyAsync(h->species.p, h->h_species32.data(), sizeof(int) * (size_t)ntotal, hipMemcpyHostToDevice, st));
+  HIP_TRY(h, hipMemcpyAsync(h->x64.p, coordinates, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyHostToDevice, st));
+  return build_list(h, ntotal, nlocal, h->species.p, h->x64.p, cutneigh, lo, hi, out_npairs, st);
 }
 
 int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates, int64_t npairs,

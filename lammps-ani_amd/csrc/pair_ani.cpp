@@ -86,7 +86,7 @@ void PairANI::create_model() {
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(nullptr));
 }
 
-/* pair_style ani cutoff model_file device [num_models] [cuaev|pyaev] [full|half] [single|double] */
+/* pair_style ani cutoff model_file device [num_models] [cuaev|pyaev] [full|half] [single|double] [hostlist|devlist] */
 void PairANI::settings(int narg, char** arg) {
   if (narg < 3) error->all(FLERR, "Illegal pair_style command");
   cutoff = utils::numeric(FLERR, arg[0], false, lmp);
@@ -111,6 +111,12 @@ void PairANI::settings(int narg, char** arg) {
     else if (strcmp(arg[6], "double") == 0) use_single = false;
     else error->all(FLERR, "precision should be single or double");
   }
+  use_devlist = false;
+  if (narg > 7) {
+    if (strcmp(arg[7], "devlist") == 0) use_devlist = true;
+    else if (strcmp(arg[7], "hostlist") != 0) error->all(FLERR, "neighbor list source should be hostlist or devlist");
+    if (use_devlist && !use_fullnbr) error->all(FLERR, "devlist builds a full neighbor list: use it with 'full'");
+  }
   create_model();
 }
 
@@ -133,7 +139,11 @@ void PairANI::init_style() {
     if (use_fullnbr) error->all(FLERR, "Pair style ANI requires newton pair off when using full neighbor list");
     error->all(FLERR, "Pair style ANI requires newton pair off when using half neighbor list");
   }
-  if (use_fullnbr)
+  if (use_devlist)
+    // the list is built on the device (ani_build_list); LAMMPS keeps its re-neighbouring schedule (neighbor->ago, ghost
+    // borders) but an occasional list is only built on demand, and we never ask
+    neighbor->add_request(this, NeighConst::REQ_FULL | NeighConst::REQ_OCCASIONAL);
+  else if (use_fullnbr)
     neighbor->add_request(this, NeighConst::REQ_FULL);
   else
     neighbor->add_request(this);
@@ -152,9 +162,26 @@ void PairANI::compute(int eflag, int vflag) {
   const int nlocal = atom->nlocal;
   const int ntotal = nlocal + atom->nghost;
   const int ago = neighbor->ago;
-  const int inum = list->inum;
+  const int inum = use_devlist ? nlocal : list->inum;
 
-  if (ago == 0) {
+  if (use_devlist) {
+    if (ago == 0) {
+      species.resize(ntotal);
+      for (int i = 0; i < ntotal; i++) species[i] = type[i] - 1;
+      // a box around owned atoms and ghosts for the cell grid (any box does: atoms outside are clamped into edge cells)
+      double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
+      for (int k = 0; k < 3; k++) {
+        double a = ntotal > 0 ? x[0][k] : 0.0, b = a;
+        for (int i = 1; i < ntotal; i++) { a = x[i][k] < a ? x[i][k] : a; b = x[i][k] > b ? x[i][k] : b; }
+        lo[k] = a - 0.25; hi[k] = b + 0.25;
+      }
+      if (ntotal > 0 &&
+          ani_build_list(ani, ntotal, nlocal, species.data(), &x[0][0], cutoff + neighbor->skin, lo, hi, &npairs) != ANI_OK)
+        error->one(FLERR, std::string("Pair ani: ") + ani_last_error(ani));
+      flat_ilist.resize(nlocal);
+      for (int i = 0; i < nlocal; i++) flat_ilist[i] = i;
+    }
+  } else if (ago == 0) {
     species.resize(ntotal);
     for (int i = 0; i < ntotal; i++) species[i] = type[i] - 1;
     const int* ilist = list->ilist;
@@ -202,7 +229,12 @@ void PairANI::compute(int eflag, int vflag) {
   if (!coords) coords = dummy;
 
   int rc;
-  if (use_fullnbr) {
+  if (use_devlist) {
+    rc = ntotal > 0 ? ani_compute_full(ani, ntotal, nlocal, nullptr, coords, npairs, nullptr, nullptr, nullptr, /*ago=*/1,
+                                       eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, out_force.data(),
+                                       eflag_atom ? out_eatom.data() : nullptr, out_virial)
+                    : ANI_OK;
+  } else if (use_fullnbr) {
     if (inum != nlocal) error->one(FLERR, "Pair ani: full neighbor list does not cover every local atom");
     rc = ani_compute_full(ani, ntotal, nlocal, species.data(), coords, npairs, flat_ilist.data(), flat_jlist.data(),
                           flat_numneigh.data(), ago, eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, out_force.data(),

@@ -2,8 +2,10 @@
    pair_style ani for LAMMPS on AMD MI355X — host adapter over the C ABI of libani_hip.so (include/ani_hip.h).
 
    Same input-script surface as the reference's PairANI (src/pair_ani.h:22-55, src/pair_ani.cpp):
-       pair_style ani <cutoff> <model_file> <device> [num_models=-1] [cuaev|pyaev] [full|half] [single|double]
+       pair_style ani <cutoff> <model_file> <device> [num_models=-1] [cuaev|pyaev] [full|half] [single|double] [hostlist|devlist]
        pair_coeff * *
+   (the eighth word is ours: `devlist` builds the full neighbour list on the GPU at re-neighbouring steps instead of
+   taking LAMMPS' host list -- LAMMPS is then asked for an occasional list only, which it never builds)
    but no libtorch, no CUDA headers: the model runtime is the HIP library behind ani_hip.h.
    Compiled only when LAMMPS headers are available (LAMMPS_HEADER_DIR, like the reference's CMakeLists.txt:28-36);
    tests/mock_lammps provides a minimal stand-in for those headers so this file is exercised without LAMMPS.
@@ -48,6 +50,7 @@ class PairANI : public Pair {
   std::string model_file, device_str;
   int use_num_models = -1;
   bool use_cuaev = true, use_fullnbr = true, use_single = true;
+  bool use_devlist = false;  // not part of the restart record (kept byte-compatible with the reference): restarts come back as hostlist
   bool profiling = false;  // LAMMPS_ANI_PROFILING: report timing honestly (the C ABI is synchronous already)
 
   // list epoch (rebuilt when neighbor->ago == 0), grown 1.5x like the reference (src/pair_ani.cpp:119-127)

@@ -79,11 +79,12 @@ class NeighList {
   int** firstneigh = nullptr;
 };
 
-namespace NeighConst { enum { REQ_DEFAULT = 0, REQ_FULL = 1 }; }
+namespace NeighConst { enum { REQ_DEFAULT = 0, REQ_FULL = 1 << 0, REQ_OCCASIONAL = 1 << 4 }; }
 
 class Neighbor {
  public:
   int ago = 0;
+  double skin = 2.0;
   int last_request = -1;
   void add_request(Pair*, int flags = 0) { last_request = flags; }
 };

@@ -101,6 +101,26 @@ def test_forces_from_device_list_match_host_list(model_cache, hip):
     ani.close()
 
 
+def test_host_array_list_build_equals_host_list(model_cache, hip):
+    """ani_build_list (host species/positions in, list built on the device) followed by the host-pointer compute at
+    ago != 0 -- what `pair_style ani ... devlist` does -- against the harness list through the same entry point."""
+    sysm = hx.random_box(2500, 7, 31.0, seed=4)
+    inp = hx.decompose(sysm, grid=(2, 2, 2), rank=5)
+    ani = hip.ANI(model_cache("ani2x", 2, 11), 0)
+    ref = ani.compute(inp, ago=0)
+    n = ani.build_list(inp.species, inp.x, inp.nlocal, 7.1)
+    assert n == inp.npairs
+    nn, jl = ani.debug_list(inp.nlocal)
+    assert np.array_equal(nn, inp.numneigh)
+    for a, b in zip(_segments(nn, jl), _segments(inp.numneigh, inp.jlist)):
+        assert np.array_equal(a, b)
+    out = ani.compute(inp, ago=1)   # list pointers are ignored at ago != 0: the installed (device-built) list is used
+    assert abs(out["energy"] - ref["energy"]) < 1e-3
+    assert np.abs(out["force"] - ref["force"]).max() < 1e-3
+    assert np.abs(out["virial"] - ref["virial"]).max() < 1e-2
+    ani.close()
+
+
 def test_build_list_argument_errors(model_cache, hip):
     import torch
     inp = hx.decompose(hx.random_box(300, 7, 16.0, seed=5))

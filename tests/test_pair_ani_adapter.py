@@ -132,3 +132,37 @@ def test_adapter_double_precision(mock, model_cache):
     assert abs(e - float(g["compat_energy"])) < 9e-9 * abs(float(g["compat_energy"]))
     np.testing.assert_allclose(f[: inp.nlocal], folded, rtol=0, atol=1e-8)
     mock.mock_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aev", ["cuaev", "pyaev"])
+def test_adapter_devlist_matches_hostlist(mock, model_cache, aev):
+    """`... full single devlist`: LAMMPS is asked for an occasional list only (never built) and the list comes from
+    ani_build_list on the device; forces / energy / virial / eatom equal the host-list run and the fp64 fixtures."""
+    g = load_golden("water30_pbc_ani2x_m8")
+    inp = golden_input(g, half=False)
+    p = golden_model_path(g, model_cache)
+    out = {}
+    for src in ("hostlist", "devlist"):
+        h = mock.mock_create(b"real", 0)
+        rc, err = _style(mock, h, ["5.1", p, "hip", "-1", aev, "full", "single", src])
+        assert rc == 0, err
+        assert mock.mock_last_request(h) == (1 if src == "hostlist" else (1 | 16))  # REQ_FULL [| REQ_OCCASIONAL]
+        for ago in (0, 1, 0):
+            out[src] = _run(mock, h, inp, ago)
+        mock.mock_destroy(h)
+    (fh, eh, vh, eah), (fd, ed, vd, ead) = out["hostlist"], out["devlist"]
+    np.testing.assert_allclose(fd, fh, rtol=0, atol=1e-3)   # same pairs, another summation order
+    assert abs(ed - eh) < 1e-3
+    np.testing.assert_allclose(vd, vh, rtol=0, atol=1e-2)
+    np.testing.assert_allclose(ead, eah, rtol=0, atol=1e-3)
+    mode = "strict" if aev == "cuaev" else "compat"
+    ref_f = g[f"{mode}_force"]
+    folded = ref_f[: inp.nlocal].copy()
+    np.add.at(folded, inp.owner_lidx, ref_f[inp.nlocal:])
+    np.testing.assert_allclose(fd[: inp.nlocal], folded, rtol=0, atol=2.3e-3)
+    h = mock.mock_create(b"real", 0)
+    rc, err = _style(mock, h, ["5.1", p, "hip", "-1", aev, "half", "single", "devlist"])
+    assert rc == 1 and "full" in err
+    rc, err = _style(mock, h, ["5.1", p, "hip", "-1", aev, "full", "single", "gpulist"])
+    assert rc == 1 and "hostlist or devlist" in err
