@@ -615,7 +615,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   }
 
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[0], st));
-  launch_pack(d_x, h->species.p, h->ntotal, h->cmap, h->xyzs.p, h->fbuf.p, h->virial_acc.p, st);  // also clears fbuf / virial_acc
+  launch_pack(d_x, h->species.p, h->ntotal, h->cmap, h->xyzs.p, h->fbuf.p, h->virial_acc.p, d_ev, st);  // also clears fbuf / virial_acc
 
   AevArgs a{};
   a.xyzs = h->xyzs.p; a.ilist = h->ilist.p; a.numneigh = h->numneigh.p; a.nbr_off = h->nbr_off.p; a.jlist = h->jlist.p;

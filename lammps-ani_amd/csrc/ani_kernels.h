@@ -68,9 +68,10 @@ inline size_t split_bf16x3_elems(int N, int K) { return (size_t)N * ((K + 15) / 
 
 // x (double [ntotal*3]) + species -> float4 {x,y,z,bits of cmap[species]}
 struct SpeciesMap { int m[kMaxSpecies]; };
-// also clears this step's accumulators: fbuf[4*ntotal] and virial_acc[kVirialSlots*9] (no separate memsets)
+// also clears this step's accumulators: fbuf[4*ntotal], virial_acc[kVirialSlots*9] and the 10 doubles of ev_zero (the
+// energy/virial output the finish kernel adds to; may be NULL) -- no separate memsets
 void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
-                 double* virial_acc, hipStream_t st);
+                 double* virial_acc, double* ev_zero, hipStream_t st);
 
 // rebuild-time preparation: neighbour offsets, species buckets.  All outputs device arrays.
 struct PrepOut {
@@ -171,7 +172,7 @@ struct FinishArgs {
   const double* virial_acc;  // [kVirialSlots][9] Hartree (unsymmetrised partial sums), or NULL
   double* f_out;         // [ntotal*3] kcal/mol/A
   int f_accumulate;      // 1: +=, 0: overwrite
-  double* ev_out;        // [10]
+  double* ev_out;        // [10]; [0] is ADDED to (zeroed by launch_pack), [1..9] written when virial_acc is given
   double* eatom_out;     // [nlocal] indexed by centre, or NULL
   double* partial;       // [256] scratch
   const int* err_flag;   // capacity overflow flag: energy becomes NaN so device-resident callers notice

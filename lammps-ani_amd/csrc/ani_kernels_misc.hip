@@ -7,9 +7,11 @@
 namespace ani {
 
 __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int ntotal, SpeciesMap cmap,
-                            float4* __restrict__ out, float* __restrict__ fbuf, double* __restrict__ virial_acc) {
+                            float4* __restrict__ out, float* __restrict__ fbuf, double* __restrict__ virial_acc,
+                            double* __restrict__ ev_zero) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 9 * kVirialSlots) virial_acc[i] = 0.0;
+  if (ev_zero && i < 10) ev_zero[i] = 0.0;   // the finish kernel ADDS its block sums of the energy
   if (i >= ntotal) return;
   // coordinates.to(dtype): src/ani_csrc/ani.cpp:206-207.  The species stored next to the position is the index the
   // AEV kernels use (compact index among the species present in this system, see ani_hip.cpp:specialize).
@@ -20,10 +22,10 @@ __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict_
 }
 
 void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
-                 double* virial_acc, hipStream_t st) {
+                 double* virial_acc, double* ev_zero, hipStream_t st) {
   const int nthr = ntotal > 9 * kVirialSlots ? ntotal : 9 * kVirialSlots;
   hipLaunchKernelGGL(pack_kernel, dim3((nthr + 255) / 256), dim3(256), 0, st, d_x, d_species, ntotal, cmap,
-                     xyzs, fbuf, virial_acc);
+                     xyzs, fbuf, virial_acc, ev_zero);
 }
 
 // ---- rebuild-time preparation ------------------------------------------------------------------------
@@ -155,77 +157,70 @@ void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numne
 }
 
 // ---- final reductions ------------------------------------------------------------------------------------
-constexpr int kFinishBlocks = 256;
+// ONE launch: blocks [0, kFinishBlocks) sum the row energies and ADD their share to ev_out[0] (zeroed by pack_kernel;
+// a few double atomics on one address), block kFinishBlocks reduces the virial rows, the rest convert the force
+// accumulators.  Three dependent launches of a few microseconds each were 6 % of a 12 500-atom step.
+constexpr int kFinishBlocks = 32;
 
-__global__ __launch_bounds__(256) void finish_energy_kernel(FinishArgs a) {
+__global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
   __shared__ double red[256];
-  double acc = 0.0;
-  for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < a.nrows; row += gridDim.x * blockDim.x) {
-    const int ii = a.centre_of_row[row];
-    if (ii < 0) continue;
-    float e = 0.f;
-    for (int m = 0; m < a.M; m++) e += a.e_rows[(long long)m * a.nrows_ld + row];
-    // energy_shifter (models/lammps_ani.py:230,250), self energy added in fp64
-    const double ea = (double)e + a.sae[a.species[a.ilist[ii]]];
-    if (a.eatom_out) a.eatom_out[ii] = ea * 627.5094738898777;
-    acc += ea;
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+  const int b = blockIdx.x;
+  if (b < kFinishBlocks) {
+    double acc = 0.0;
+    for (int row = b * blockDim.x + threadIdx.x; row < a.nrows; row += kFinishBlocks * blockDim.x) {
+      const int ii = a.centre_of_row[row];
+      if (ii < 0) continue;
+      float e = 0.f;
+      for (int m = 0; m < a.M; m++) e += a.e_rows[(long long)m * a.nrows_ld + row];
+      // energy_shifter (models/lammps_ani.py:230,250), self energy added in fp64
+      const double ea = (double)e + a.sae[a.species[a.ilist[ii]]];
+      if (a.eatom_out) a.eatom_out[ii] = ea * 627.5094738898777;
+      acc += ea;
+    }
+    red[threadIdx.x] = acc;
     __syncthreads();
-  }
-  if (threadIdx.x == 0) a.partial[blockIdx.x] = red[0];
-}
-
-__global__ __launch_bounds__(256) void finish_final_kernel(FinishArgs a) {
-  __shared__ double red[256];
-  red[threadIdx.x] = threadIdx.x < kFinishBlocks ? a.partial[threadIdx.x] : 0.0;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) a.ev_out[0] = (a.err_flag && *a.err_flag) ? __longlong_as_double(0x7ff8000000000000LL) : red[0] * 627.5094738898777;
-  // virial: sum the partial rows, then (virial.t() + virial)/2 : models/lammps_ani.py:200
-  if (!a.virial_acc) {   // kernel-argument uniform
-    if (threadIdx.x < 9) a.ev_out[1 + threadIdx.x] = 0.0;
-    return;
-  }
-  __shared__ double vsum[9];
-  __syncthreads();
-  for (int c = 0; c < 9; c++) {
-    double t = 0.0;
-    for (int sl = threadIdx.x; sl < kVirialSlots; sl += blockDim.x) t += a.virial_acc[9 * sl + c];
-    red[threadIdx.x] = t;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-      if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0) vsum[c] = red[0];
-    __syncthreads();
+    if (threadIdx.x == 0) {
+      // a capacity overflow turns the energy into NaN so that device-resident callers notice
+      const bool bad = b == 0 && a.err_flag && *a.err_flag;
+      atomicAdd(&a.ev_out[0], bad ? __longlong_as_double(0x7ff8000000000000LL) : red[0] * 627.5094738898777);
+    }
+    return;
   }
-  if (threadIdx.x < 9) {
-    const int k = threadIdx.x / 3, l = threadIdx.x % 3;
-    a.ev_out[1 + threadIdx.x] = 0.5 * (vsum[3 * k + l] + vsum[3 * l + k]) * 627.5094738898777;
+  if (b == kFinishBlocks) {
+    // virial: sum the partial rows, then (virial.t() + virial)/2 : models/lammps_ani.py:200
+    if (!a.virial_acc) return;   // ev_out[1..9] stay zero
+    __shared__ double vsum[9];
+    for (int c = 0; c < 9; c++) {
+      double t = 0.0;
+      for (int sl = threadIdx.x; sl < kVirialSlots; sl += blockDim.x) t += a.virial_acc[9 * sl + c];
+      red[threadIdx.x] = t;
+      __syncthreads();
+      for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) vsum[c] = red[0];
+      __syncthreads();
+    }
+    if (threadIdx.x < 9) {
+      const int k = threadIdx.x / 3, l = threadIdx.x % 3;
+      a.ev_out[1 + threadIdx.x] = 0.5 * (vsum[3 * k + l] + vsum[3 * l + k]) * 627.5094738898777;
+    }
+    return;
   }
-}
-
-__global__ void finish_force_kernel(const float* __restrict__ fbuf, int n3, double* __restrict__ f_out, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n3) return;
-  const double v = (double)fbuf[4 * (i / 3) + (i % 3)] * 627.5094738898777;  // accumulators are one float4 per atom
-  f_out[i] = accumulate ? f_out[i] + v : v;
+  const int i = (b - kFinishBlocks - 1) * blockDim.x + threadIdx.x;
+  if (i >= 3 * a.ntotal) return;
+  const double v = (double)a.fbuf[4 * (i / 3) + (i % 3)] * 627.5094738898777;  // accumulators are one float4 per atom
+  a.f_out[i] = a.f_accumulate ? a.f_out[i] + v : v;
 }
 
 void launch_finish(const FinishArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(finish_energy_kernel, dim3(kFinishBlocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(finish_final_kernel, dim3(1), dim3(256), 0, st, a);
-  const int n3 = a.ntotal * 3;
-  if (n3 > 0 && a.f_out)
-    hipLaunchKernelGGL(finish_force_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, a.fbuf, n3, a.f_out, a.f_accumulate);
+  const int n3 = a.f_out ? a.ntotal * 3 : 0;
+  hipLaunchKernelGGL(finish_kernel, dim3(kFinishBlocks + 1 + (n3 + 255) / 256), dim3(256), 0, st, a);
 }
 
 }  // namespace ani
