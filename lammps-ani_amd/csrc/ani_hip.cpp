@@ -491,7 +491,13 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
   const int np = (int)layer_probs[0].size();
   int tiles = 0;
   for (const GemmArgs& g : layer_probs[0]) tiles += g.rows / 64;
-  bool chain = h->mlp_chain && h->mlp_split && M == 1 && np > 0 && (h->mlp_chain > 1 || tiles <= mlp_chain_slots());
+  // Which is faster is a matter of rounds: the chained kernel holds 2 workgroups per CU for all six products, a grouped
+  // launch 3 per CU for one.  Measured per round at the benchmark shapes: 0.106 ms (chain) and 0.137 ms (six launches);
+  // e.g. 780 tiles (50 000 water atoms) are 2 rounds either way -> chain; 1564 tiles are 4 against 3 -> grouped launches.
+  const int cslots = mlp_chain_slots(), lslots = cslots + cslots / 2;
+  const bool chain_wins = tiles <= cslots || (tiles <= 2 * cslots &&   // beyond two rounds the two were within 4 %: launches
+                                              0.106 * ((tiles + cslots - 1) / cslots) < 0.137 * ((tiles + lslots - 1) / lslots));
+  bool chain = h->mlp_chain && h->mlp_split && M == 1 && np > 0 && (h->mlp_chain > 1 || chain_wins);
   for (const auto& lp : layer_probs) chain = chain && (int)lp.size() == np;
   if (chain) {
     std::vector<GemmArgs> flat;
