@@ -98,6 +98,8 @@ struct ani_handle {
   DevBuf<float4> xyzs;
   DevBuf<int4> row_info;
   DevBuf<double> x64, f64, ev, eatom, partial, virial_acc;
+  DevBuf<double> origin;       // [3] the fp32 positions of an epoch are relative to this point (set at its first step)
+  bool need_origin = true;
   DevBuf<double> rep_tables, erep;  // optional pairwise repulsion: tables of the model file, energy partial sums
   DevBuf<float> aev, gaev, act, e_rows, fbuf;
   DevBuf<double> aev64, gaev64, act64, e_rows64, fbuf64;  // precision 'double'
@@ -317,6 +319,7 @@ int specialize(ani_handle* h, int mask) {
 // d_species/d_ilist/d_numneigh/d_jlist already hold this epoch's list in the handle's own buffers.
 int rebuild(ani_handle* h, hipStream_t st) {
   const HostModel& m = h->model;
+  h->need_origin = true;
   const int nlocal = h->nlocal;
   const int nrows_cap = round_up(nlocal, kRowTile) + m.S * kRowTile;
   HIP_TRY(h, h->nbr_off.reserve((size_t)nlocal + 1));
@@ -621,7 +624,12 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   }
 
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[0], st));
-  launch_pack(d_x, h->species.p, h->ntotal, h->cmap, h->xyzs.p, h->fbuf.p, h->virial_acc.p, d_ev, st);  // also clears fbuf / virial_acc
+  HIP_TRY(h, h->origin.reserve(3));
+  if (h->need_origin) {
+    launch_origin(d_x, h->ntotal, h->origin.p, st);
+    h->need_origin = false;
+  }
+  launch_pack(d_x, h->species.p, h->ntotal, h->cmap, h->xyzs.p, h->fbuf.p, h->virial_acc.p, d_ev, h->origin.p, st);  // also clears fbuf / virial_acc
 
   AevArgs a{};
   a.xyzs = h->xyzs.p; a.ilist = h->ilist.p; a.numneigh = h->numneigh.p; a.nbr_off = h->nbr_off.p; a.jlist = h->jlist.p;
@@ -775,7 +783,7 @@ void ani_destroy(ani_handle* h) {
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
   h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
-  h->xyzs.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release();
+  h->xyzs.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release(); h->origin.release();
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();

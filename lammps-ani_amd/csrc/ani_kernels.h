@@ -70,8 +70,10 @@ inline size_t split_bf16x3_elems(int N, int K) { return (size_t)N * ((K + 15) / 
 struct SpeciesMap { int m[kMaxSpecies]; };
 // also clears this step's accumulators: fbuf[4*ntotal], virial_acc[kVirialSlots*9] and the 10 doubles of ev_zero (the
 // energy/virial output the finish kernel adds to; may be NULL) -- no separate memsets
+// positions are stored relative to d_origin[3] (device; launch_origin sets it to the midpoint of the atoms' bounding box)
+void launch_origin(const double* d_x, int ntotal, double* d_origin, hipStream_t st);
 void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
-                 double* virial_acc, double* ev_zero, hipStream_t st);
+                 double* virial_acc, double* ev_zero, const double* d_origin, hipStream_t st);
 
 // rebuild-time preparation: neighbour offsets, species buckets.  All outputs device arrays.
 struct PrepOut {

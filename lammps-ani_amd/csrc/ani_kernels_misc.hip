@@ -6,26 +6,62 @@
 
 namespace ani {
 
+// Midpoint of the bounding box of all atoms of the rank, once per list epoch.  The fp32 copies of the positions are
+// taken relative to it: a sub-domain that sits 150 A from the origin of the simulation box would otherwise carry four
+// times the rounding error of one that contains it (fp32 ulp 1.5e-5 A against 3.8e-6 A; the reference converts absolute
+// coordinates, src/ani_csrc/ani.cpp:206-207).  Only differences of positions enter the AEVs, so nothing else changes.
+__global__ __launch_bounds__(1024) void origin_kernel(const double* __restrict__ x, int ntotal, double* __restrict__ origin) {
+  __shared__ double lo[3][16], hi[3][16];
+  double a[3] = {1e300, 1e300, 1e300}, b[3] = {-1e300, -1e300, -1e300};
+  for (int i = threadIdx.x; i < ntotal; i += blockDim.x)
+    for (int k = 0; k < 3; k++) {
+      const double v = x[3 * (long long)i + k];
+      a[k] = v < a[k] ? v : a[k];
+      b[k] = v > b[k] ? v : b[k];
+    }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < 3; k++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const double oa = __shfl_xor(a[k], off), ob = __shfl_xor(b[k], off);
+      a[k] = oa < a[k] ? oa : a[k];
+      b[k] = ob > b[k] ? ob : b[k];
+    }
+    if (lane == 0) { lo[k][wave] = a[k]; hi[k][wave] = b[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    double m = lo[k][0], M = hi[k][0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) { m = lo[k][w] < m ? lo[k][w] : m; M = hi[k][w] > M ? hi[k][w] : M; }
+    origin[k] = ntotal > 0 ? 0.5 * (m + M) : 0.0;
+  }
+}
+
+void launch_origin(const double* d_x, int ntotal, double* d_origin, hipStream_t st) {
+  hipLaunchKernelGGL(origin_kernel, dim3(1), dim3(1024), 0, st, d_x, ntotal, d_origin);
+}
+
 __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int ntotal, SpeciesMap cmap,
                             float4* __restrict__ out, float* __restrict__ fbuf, double* __restrict__ virial_acc,
-                            double* __restrict__ ev_zero) {
+                            double* __restrict__ ev_zero, const double* __restrict__ origin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 9 * kVirialSlots) virial_acc[i] = 0.0;
   if (ev_zero && i < 10) ev_zero[i] = 0.0;   // the finish kernel ADDS its block sums of the energy
   if (i >= ntotal) return;
-  // coordinates.to(dtype): src/ani_csrc/ani.cpp:206-207.  The species stored next to the position is the index the
-  // AEV kernels use (compact index among the species present in this system, see ani_hip.cpp:specialize).
+  // coordinates.to(dtype): src/ani_csrc/ani.cpp:206-207, relative to the epoch's origin.  The species stored next to the
+  // position is the index the AEV kernels use (compact index among the species present, see ani_hip.cpp:specialize).
   const int sp = species[i];
   const int cs = (sp >= 0 && sp < kMaxSpecies) ? cmap.m[sp] : 0;
-  out[i] = make_float4((float)x[3 * i], (float)x[3 * i + 1], (float)x[3 * i + 2], __int_as_float(cs));
+  out[i] = make_float4((float)(x[3 * i] - origin[0]), (float)(x[3 * i + 1] - origin[1]), (float)(x[3 * i + 2] - origin[2]),
+                       __int_as_float(cs));
   reinterpret_cast<float4*>(fbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
-                 double* virial_acc, double* ev_zero, hipStream_t st) {
+                 double* virial_acc, double* ev_zero, const double* d_origin, hipStream_t st) {
   const int nthr = ntotal > 9 * kVirialSlots ? ntotal : 9 * kVirialSlots;
   hipLaunchKernelGGL(pack_kernel, dim3((nthr + 255) / 256), dim3(256), 0, st, d_x, d_species, ntotal, cmap,
-                     xyzs, fbuf, virial_acc, ev_zero);
+                     xyzs, fbuf, virial_acc, ev_zero, d_origin);
 }
 
 // ---- rebuild-time preparation ------------------------------------------------------------------------
