@@ -220,3 +220,29 @@ def test_chained_mlp_launch_equals_per_layer_launches(model_cache, hip):
         assert abs(a["energy"] - b["energy"]) < 1e-3 * max(1.0, inp.nlocal / 1000.0)
         assert np.abs(a["eatom"] - b["eatom"]).max() < 1e-4
         ani.close()
+
+
+def test_energy_is_extensive_under_periodic_replication(model_cache, hip):
+    """Two periodic copies of a box side by side: E = 2 E(base) and every atom's force repeats -- a property that needs
+    no oracle (tools/big_probe.py runs it with 8 copies = 10^6 atoms).  The copy sits a box length away from the origin:
+    with absolute fp32 coordinates its rounding would differ from the base box's; the epoch origin keeps them alike."""
+    base = hx.spatial_sort(hx.water_box(6000, seed=21))
+    L = base.boxhi - base.boxlo
+    shift = np.array([L[0], 0.0, 0.0])
+    hi2 = base.boxhi + shift
+    tiled = hx.System(np.concatenate([base.x, base.x + shift]), np.tile(base.types, 2), base.boxlo, hi2)
+    ani = hip.ANI(model_cache("ani2x", 2, 11), 0)
+    def total_force(system):
+        inp = hx.decompose(system)
+        out = ani.compute(inp, ago=0)
+        f = out["force"][: inp.nlocal].copy()
+        np.add.at(f, inp.owner_lidx, out["force"][inp.nlocal:])   # ghost images' shares go home (the reverse communication)
+        return out["energy"], f
+
+    ea, fa = total_force(base)
+    eb, fb = total_force(tiled)
+    n = len(base.x)
+    assert abs(eb - 2.0 * ea) < 1e-9 * abs(ea) + 2e-2
+    assert np.abs(fb[:n] - fa).max() < 0.5 * F_TOL
+    assert np.abs(fb[n:] - fa).max() < 0.5 * F_TOL
+    ani.close()
