@@ -145,6 +145,96 @@ __global__ __launch_bounds__(512, 1) void bs(const float* __restrict__ A, int ld
   }
 }
 
+// Dynamic strip queue: the waves of all workgroups of one column block draw 32-row strips from a counter (one returning
+// atomic per strip, drawn a strip ahead), so that no wave ends a whole strip later than the others.
+template <int D>
+__global__ __launch_bounds__(512, 1) void bsq(const float* __restrict__ A, int lda, const uint4* __restrict__ B3, float* __restrict__ C,
+                                             int ldc, int rows, int N, int K, int ncb, int* __restrict__ ctr) {
+  extern __shared__ uint4 lds4[];
+  unsigned char* Bs = reinterpret_cast<unsigned char*>(lds4);
+  const int nkb = (K + 15) >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int j = blockIdx.x >> 3, per_xcd = gridDim.x >> 3, gx = per_xcd / ncb;
+  if (j >= gx * ncb) return;
+  const int cb = j % ncb;
+  const int ncols = min(64, N - 64 * cb);
+  for (int c = tid; c < nkb * 64 * 6; c += 512) {
+    const int q = c % 6, col = (c / 6) & 63, kb = c / (6 * 64);
+    const uint4 v = col < ncols ? B3[((long long)kb * N + 64 * cb + col) * 6 + q] : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(Bs + (kb * 64 + col) * ROW + q * 16) = v;
+  }
+  __syncthreads();
+  const int ntiles = rows >> 5;
+  auto ticket = [&]() {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(&ctr[cb], 1);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
+  int ct = ticket();         // strip being multiplied
+  int lt = ct, lkb = 0;      // next (strip, k-block) to request
+  int nxt = ticket();        // the strip after lt
+  int ct_next = nxt;
+  float4 pa[D][2];
+  auto issue = [&](int slot) {
+    if (lt < ntiles) {
+      const float* p = A + (long long)(32 * lt + lr) * lda + lkb * 16 + lh * 8;
+      pa[slot][0] = *reinterpret_cast<const float4*>(p);
+      pa[slot][1] = *reinterpret_cast<const float4*>(p + 4);
+    }
+    if (++lkb == nkb) { lkb = 0; lt = nxt; ct_next = nxt; nxt = lt < ntiles ? ticket() : ntiles; }
+  };
+#pragma unroll
+  for (int d = 0; d < D; d++) issue(d);
+  f32x16 acc[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
+  int ckb = 0;
+  const int ntc = (ncols + 31) >> 5;
+  while (ct < ntiles) {
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+      if (ct < ntiles) {
+        uint4 ah, am, al;
+        split8(pa[u][0], pa[u][1], ah, am, al);
+        issue(u);
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          if (c < ntc) {
+            const unsigned char* bp = Bs + (ckb * 64 + 32 * c + lr) * ROW + lh * 16;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
+            const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 64));
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, bm, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, bh, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, bl, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, bh, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, bm, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, bh, acc[c], 0, 0, 0);
+          }
+        }
+        if (++ckb == nkb) {
+          const int mbase = 32 * ct + 4 * lh;
+#pragma unroll
+          for (int c = 0; c < 2; c++) {
+            const int col = 64 * cb + 32 * c + lr;
+            if (c < ntc && col < N) {
+#pragma unroll
+              for (int r = 0; r < 16; r++) C[(long long)(mbase + (r & 3) + 8 * (r >> 2)) * ldc + col] = acc[c][r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
+          }
+          ckb = 0;
+          ct = ct_next;   // wrong if the loader has already moved two strips on: it cannot, D < nkb
+        }
+      }
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const int rows = argc > 1 ? atoi(argv[1]) : 66688;
   const int N = argc > 2 ? atoi(argv[2]) : 256;
@@ -182,7 +272,9 @@ int main(int argc, char** argv) {
   hipFuncSetAttribute((const void*)bs<2, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute((const void*)bs<2, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute((const void*)bs<2, 0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  for (int variant = 0; variant < 7; variant++) {
+  int* ctr; hipMalloc(&ctr, 64);
+  hipFuncSetAttribute((const void*)bsq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  for (int variant = 0; variant < 8; variant++) {
     auto launch = [&]() {
       if (variant == 0) hipLaunchKernelGGL((bs<2, 0>), dim3(grid), dim3(512), lds, 0, A, K, B3, C, N, rows, N, K, ncb);
       else if (variant == 1) hipLaunchKernelGGL((bs<2, 1>), dim3(grid), dim3(512), lds, 0, At, rows, B3, C, rows, rows, N, K, ncb);
@@ -190,7 +282,8 @@ int main(int argc, char** argv) {
       else if (variant == 3) hipLaunchKernelGGL((bs<2, 0, 1>), dim3(grid), dim3(512), lds, 0, A, K, B3, C, N, rows, N, K, ncb);
       else if (variant == 4) hipLaunchKernelGGL((bs<2, 0, 2>), dim3(grid), dim3(512), lds, 0, A, K, B3, C, N, rows, N, K, ncb);
       else if (variant == 5) hipLaunchKernelGGL((bs<2, 0, 4>), dim3(grid), dim3(512), lds, 0, A, K, B3, C, N, rows, N, K, ncb);
-      else hipLaunchKernelGGL((bs<2, 0, 7>), dim3(grid), dim3(512), lds, 0, A, K, B3, C, N, rows, N, K, ncb);
+      else if (variant == 6) hipLaunchKernelGGL((bs<2, 0, 7>), dim3(grid), dim3(512), lds, 0, A, K, B3, C, N, rows, N, K, ncb);
+      else { hipMemsetAsync(ctr, 0, 64, 0); hipLaunchKernelGGL((bsq<2>), dim3(grid), dim3(512), lds, 0, A, K, B3, C, N, rows, N, K, ncb, ctr); }
     };
     hipMemset(C, 0, (size_t)rows * N * 4);
     for (int i = 0; i < 3; i++) launch();
@@ -207,10 +300,10 @@ int main(int argc, char** argv) {
       const int m = (int)(((long long)t * 7919) % rows), n = (t * 104729) % N;
       double acc = 0;
       for (int k = 0; k < K; k++) acc += (double)hA[(size_t)m * K + k] * hB[(size_t)n * K + k];
-      maxerr = fmax(maxerr, fabs(acc - (variant == 0 ? hC[(size_t)m * N + n] : hC[(size_t)n * rows + m])));
+      maxerr = fmax(maxerr, fabs(acc - ((variant == 0 || variant >= 3) ? hC[(size_t)m * N + n] : hC[(size_t)n * rows + m])));
     }
     const double fl = 2.0 * rows * N * K;
-    printf("%s rows=%d N=%d K=%d  %.3f ms  %.1f TFLOP/s algorithmic  maxerr=%.2e  (A x ncb + C: %.0f MB -> %.2f TB/s)\n", variant == 0 ? "row-major D=2" : variant == 1 ? "feat-major D=2" : variant == 2 ? "feat-major D=4" : variant == 3 ? "ABL no A loads" : variant == 4 ? "ABL no split" : variant == 5 ? "ABL B frag fixed" : "ABL all three",
+    printf("%s rows=%d N=%d K=%d  %.3f ms  %.1f TFLOP/s algorithmic  maxerr=%.2e  (A x ncb + C: %.0f MB -> %.2f TB/s)\n", variant == 0 ? "row-major D=2" : variant == 1 ? "feat-major D=2" : variant == 2 ? "feat-major D=4" : variant == 3 ? "ABL no A loads" : variant == 4 ? "ABL no split" : variant == 5 ? "ABL B frag fixed" : variant == 6 ? "ABL all three" : "dynamic strip queue",
            rows, N, K, ms, fl / ms / 1e9, maxerr, (rows * (double)(K * ncb + N) * 4) / 1e6, rows * (double)(K * ncb + N) * 4 / ms / 1e9);
   }
   return 0;
