@@ -97,7 +97,7 @@ struct ani_handle {
   DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
   DevBuf<float4> xyzs;
   DevBuf<int4> row_info;
-  DevBuf<double> x64, f64, ev, eatom, partial, virial_acc;
+  DevBuf<double> x64, f64, ev, eatom, virial_acc;
   DevBuf<double> origin;       // [3] the fp32 positions of an epoch are relative to this point (set at its first step)
   bool need_origin = true;
   DevBuf<double> rep_tables, erep;  // optional pairwise repulsion: tables of the model file, energy partial sums
@@ -610,7 +610,6 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   const HostModel& m = h->model;
   HIP_TRY(h, h->xyzs.reserve(h->ntotal));
   HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 4));  // one float4 per atom
-  HIP_TRY(h, h->partial.reserve(256));
   HIP_TRY(h, h->virial_acc.reserve(9 * kVirialSlots));
   HIP_TRY(h, h->err_flag.reserve(1, true));
   if (h->timing) {
@@ -679,7 +678,6 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   fa.virial_acc = vflag ? h->virial_acc.p : nullptr;
   fa.f_out = d_f; fa.f_accumulate = f_accumulate; fa.ev_out = d_ev;
   fa.eatom_out = eflag_atom ? d_eatom : nullptr;
-  fa.partial = h->partial.p;
   fa.err_flag = h->err_flag.p;
   launch_finish(fa, st);
   if (m.has_rep) launch_repulsion_energy(h->erep.p, kVirialSlots, d_ev, st);
@@ -783,7 +781,7 @@ void ani_destroy(ani_handle* h) {
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
   h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
-  h->xyzs.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->partial.release(); h->origin.release();
+  h->xyzs.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->origin.release();
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();

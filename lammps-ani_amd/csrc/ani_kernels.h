@@ -176,7 +176,6 @@ struct FinishArgs {
   int f_accumulate;      // 1: +=, 0: overwrite
   double* ev_out;        // [10]; [0] is ADDED to (zeroed by launch_pack), [1..9] written when virial_acc is given
   double* eatom_out;     // [nlocal] indexed by centre, or NULL
-  double* partial;       // [256] scratch
   const int* err_flag;   // capacity overflow flag: energy becomes NaN so device-resident callers notice
 };
 void launch_finish(const FinishArgs& a, hipStream_t st);

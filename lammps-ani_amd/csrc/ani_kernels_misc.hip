@@ -193,10 +193,10 @@ void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numne
 }
 
 // ---- final reductions ------------------------------------------------------------------------------------
-// ONE launch: blocks [0, kFinishBlocks) sum the row energies and ADD their share to ev_out[0] (zeroed by pack_kernel;
+// ONE launch: blocks [0, kFinishBlocks) sum the row energies (enough blocks that each walks its rows in a few dependent loads) and ADD their share to ev_out[0] (zeroed by pack_kernel;
 // a few double atomics on one address), block kFinishBlocks reduces the virial rows, the rest convert the force
 // accumulators.  Three dependent launches of a few microseconds each were 6 % of a 12 500-atom step.
-constexpr int kFinishBlocks = 32;
+constexpr int kFinishBlocks = 128;
 
 __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
   __shared__ double red[256];
