@@ -61,13 +61,13 @@ def aev_bytes_per_step(A, nlocal, ntotal, npairs):
 class Workload:
     """One water box on this rank: system, decomposition, device tensors, library handle, ghost exchange."""
 
-    def __init__(self, atoms, models, aev, rank, world, dev, dev_index, vflag, repulsion=False):
+    def __init__(self, atoms, models, aev, rank, world, dev, dev_index, vflag, repulsion=False, kind="ani2x", system=None):
         self.atoms, self.models, self.world, self.vflag = atoms, models, world, vflag
-        self.model = mf.synthetic_model("ani2x", models, seed=2024, repulsion=repulsion)
-        self.mpath = f"/tmp/bench_ani2x_m{models}_r{rank}.anim"
+        self.model = mf.synthetic_model(kind, models, seed=2024, repulsion=repulsion)
+        self.mpath = f"/tmp/bench_{kind}_m{models}_r{rank}.anim"
         mf.write_model(self.mpath, self.model)
         # LAMMPS sorts atoms spatially (atom_modify sort): neighbours are then close in memory
-        self.system = hx.spatial_sort(hx.water_box(atoms, seed=12345))
+        self.system = hx.spatial_sort(hx.water_box(atoms, seed=12345) if system is None else system)
         self.grid = comm.grid_for(world)
         self.inp = inp = hx.decompose(self.system, self.grid, rank, cutoff=5.1, skin=2.0)
         self.ani = ani_hip.ANI(self.mpath, dev_index, -1, use_cuaev=(aev == "cuaev"), use_fullnbr=True, use_single=True)
@@ -337,6 +337,19 @@ def main():
                                "ms_per_step": dt2 / args.steps * 1e3, "value": args.steps / dt2 * 0.0432, "unit": "ns/day",
                                "phase_ms": {k: ph2[k] / c2 for k in ("aev_fwd", "mlp", "aev_bwd")}}
         w2.close()
+        # BASELINE.json configs[4] shape on one GPU: reactive CH4:O2 gas (3 of the 4 ANI-1x species present, ~26 list
+        # entries per atom), ANI-1x shaped 8-member ensemble with the pairwise repulsion of the reactive models
+        sysm = hx.combustion_box(100008, seed=12345)
+        w3 = Workload(len(sysm.x), 8, args.aev, rank, world, dev, dev_index, args.vflag, repulsion=True, kind="ani1x", system=sysm)
+        dt3, ph3 = w3.timed_run(args.steps, args.warmup)
+        c3 = max(ph3["calls"], 1)
+        out["mixed_species_config"] = {
+            "workload": f"CH4:O2 1:2 gas, 0.25 g/cm3, {len(sysm.x)} atoms (H,C,O of the 4 ANI-1x species; BASELINE.json configs[4] "
+                        "shape on one GPU), ANI-1x shaped, 8 models, pairwise repulsion on",
+            "ms_per_step": dt3 / args.steps * 1e3, "value": args.steps / dt3 * 0.0432, "unit": "ns/day",
+            "npairs_per_atom": w3.inp.npairs / max(w3.inp.nlocal, 1), "aev_columns": w3.ani.debug_view().aev_active_length,
+            "phase_ms": {k: ph3[k] / c3 for k in ("aev_fwd", "mlp", "aev_bwd")}}
+        w3.close()
     if rank == 0 and world == 1 and not args.no_md:
         out["md_loop"] = md_loop_pass(system, args.models, args.aev, dev, dev_index, args.md_steps, 20)
     if rank == 0:

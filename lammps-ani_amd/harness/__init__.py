@@ -235,6 +235,42 @@ def water_box(n_atoms: int, seed: int = 12345, density: float = 0.98, type_H: in
     return System(x, types, lo, hi)
 
 
+def combustion_box(n_atoms: int, seed: int = 12345, density: float = 0.25, type_H: int = 1, type_C: int = 2,
+                   type_O: int = 4) -> System:
+    """Synthetic CH4 : O2 = 1 : 2 gas at 0.25 g/cm^3 (the reactive box of
+    examples/combustion/prepare_system/generate_pdb.py:27-52): rigid methane (r_CH 1.09 A, tetrahedral) and oxygen
+    (r_OO 1.21 A) molecules, centres on a jittered simple-cubic lattice (sigma 0.5 A), random orientations.  n_atoms is
+    rounded down to whole groups of 9 atoms (C H4 + 2 O2); ~26 neighbours within 7.1 A."""
+    rng = np.random.default_rng(seed)
+    ngroup = n_atoms // 9
+    nmol = 3 * ngroup
+    mass_g = ngroup * (12.011 + 4 * 1.008 + 4 * 15.999) / 6.0221408e23
+    L = (mass_g / density * 1e24) ** (1.0 / 3.0)
+    ncell = int(np.ceil(nmol ** (1.0 / 3.0)))
+    idx = rng.permutation(ncell ** 3)[:nmol]
+    centres = (np.stack([idx % ncell, (idx // ncell) % ncell, idx // (ncell * ncell)], 1) + 0.5) * (L / ncell)
+    centres += rng.normal(0.0, 0.5, size=(nmol, 3))
+    q = rng.normal(size=(nmol, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w_, x_, y_, z_ = q.T
+    R = np.stack([np.stack([1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - z_ * w_), 2 * (x_ * z_ + y_ * w_)], 1),
+                  np.stack([2 * (x_ * y_ + z_ * w_), 1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - x_ * w_)], 1),
+                  np.stack([2 * (x_ * z_ - y_ * w_), 2 * (y_ * z_ + x_ * w_), 1 - 2 * (x_ * x_ + y_ * y_)], 1)], 1)
+    t = 1.09 / np.sqrt(3.0)
+    ch4 = np.array([[0, 0, 0], [t, t, t], [t, -t, -t], [-t, t, -t], [-t, -t, t]], dtype=np.float64)
+    o2 = np.array([[0.605, 0, 0], [-0.605, 0, 0]], dtype=np.float64)
+    pos, types = [], []
+    for g in range(ngroup):
+        for k, (tmpl, ty) in enumerate(((ch4, [type_C] + [type_H] * 4), (o2, [type_O] * 2), (o2, [type_O] * 2))):
+            mi = 3 * g + k
+            pos.append(centres[mi] + tmpl @ R[mi].T)
+            types.extend(ty)
+    x = np.mod(np.concatenate(pos), L)
+    x[x >= L] = 0.0
+    lo, hi = np.full(3, -L / 2), np.full(3, L / 2)
+    return System(x + lo, np.asarray(types, dtype=np.int32), lo, hi)
+
+
 def random_box(n_atoms: int, ntypes: int, L: float, seed: int = 7, min_dist: float = 0.9) -> System:
     """Mixed-species random box (rejection on a minimum distance) — exercises every species bucket."""
     rng = np.random.default_rng(seed)
