@@ -493,11 +493,15 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
 // Chained MLP for small systems: one workgroup carries a 64-row tile through all the layers (see ani_kernels.h).
 // The tile loop of a layer is the one of gemm_grouped_x3<2, *, 1, 1>.
 // ---------------------------------------------------------------------------------------------------------------
-// WM = 2: 64-row tiles, 2x2 waves;  WM = 1: 32-row tiles, 1x4 waves (twice the workgroups when even 64-row tiles leave CUs idle)
-template <int WM>
-__global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restrict__ layers, const int* __restrict__ epi,
-                                                        const int* __restrict__ tile_start, int nlayers, int nprob) {
-  constexpr int WN = 4 / WM, R = 32 * WM, NTW = 8 / WN, ROW = 112;
+// WM = 2: 64-row tiles.  NWV = 4: 2x2 waves, two workgroups per CU.  NWV = 8: 2x4 waves, ONE 512-thread workgroup per
+// CU, for systems with no more tiles than CUs: every tile streams all the weights from L2 (1.35 MB for the six ANI-2x
+// products of a species), so 32-row tiles for twice the workgroups doubled that traffic (5.9 TB/s at 12 500 atoms), while
+// a lone 4-wave workgroup on 64 rows ran each wave's instruction stream twice as long; eight waves halve both.
+template <int WM, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const GemmArgs* __restrict__ layers, const int* __restrict__ epi,
+                                                                           const int* __restrict__ tile_start, int nlayers, int nprob) {
+  constexpr int NT = 64 * NWV, WN = NWV / WM, R = 32 * WM, NTW = 8 / WN, ROW = 112;
+  constexpr int NB = 6 * 256 / NT;   // 16-byte chunks of a Bt slab per thread
   // two LDS stages: slab k+1 is written while slab k is multiplied and slab k+2 is in flight in registers -- one barrier
   // per slab, and every load has a whole slab to arrive.  (At most two of these workgroups share a CU.)
   constexpr int STAGE = (R + 256) * ROW;
@@ -532,28 +536,31 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restric
       for (int nt = 0; nt < NTW; nt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
-      float4 pa, pm;
-      uint4 pb[6];
-      auto gload = [&](int kb) {
+      // Two register sets of loads in flight: the set written to LDS in step kt was requested in step kt - 2.  A lone
+      // workgroup per CU (small systems) is bound by the latency of these loads, not by the matrix pipe: with one set
+      // (one slab of lead) a slab took ~1.2 us whatever the tile height.
+      struct Regs { float4 pa, pm; uint4 pb[NB]; };
+      Regs r0, r1;
+      auto gload = [&](int kb, Regs& q) {
         const int kc = kb * 16 + ak;
         const bool in = kc < K && ar < R;
-        pa = in ? *reinterpret_cast<const float4*>(A + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
-        if (Am) pm = in ? *reinterpret_cast<const float4*>(Am + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
+        q.pa = in ? *reinterpret_cast<const float4*>(A + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
+        if (Am) q.pm = in ? *reinterpret_cast<const float4*>(Am + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
         const uint4* src = B3 + ((long long)kb * N + n0) * 6;
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-          const int c = tid + 256 * i;
-          pb[i] = (kb < nkt && c < 6 * brows) ? src[c] : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < NB; i++) {
+          const int c = tid + NT * i;
+          q.pb[i] = (kb < nkt && c < 6 * brows) ? src[c] : make_uint4(0, 0, 0, 0);
         }
       };
-      auto stage_write = [&](int st) {
+      auto stage_write = [&](int st, const Regs& q) {
         unsigned char* As = lds + st * STAGE;
         unsigned char* Bs = As + R * ROW;
         if (ar < R) {
-          float4 av = pa;
+          float4 av = q.pa;
           if (Am) {
-            av.x *= dcelu_from_h(pm.x, g.inv_alpha); av.y *= dcelu_from_h(pm.y, g.inv_alpha);
-            av.z *= dcelu_from_h(pm.z, g.inv_alpha); av.w *= dcelu_from_h(pm.w, g.inv_alpha);
+            av.x *= dcelu_from_h(q.pm.x, g.inv_alpha); av.y *= dcelu_from_h(q.pm.y, g.inv_alpha);
+            av.z *= dcelu_from_h(q.pm.z, g.inv_alpha); av.w *= dcelu_from_h(q.pm.w, g.inv_alpha);
           }
           unsigned h[4], m[4], lo[4];
           split3(av.x, h[0], m[0], lo[0]); split3(av.y, h[1], m[1], lo[1]);
@@ -564,21 +571,14 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restric
           *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-          const int c = tid + 256 * i;
-          const int r = c / 6, q = c - 6 * r;
-          if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + q * 16) = pb[i];
+        for (int i = 0; i < NB; i++) {
+          const int c = tid + NT * i;
+          const int r = c / 6, q6 = c - 6 * r;
+          if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + q6 * 16) = q.pb[i];
         }
       };
-      gload(0);
-      stage_write(0);
-      if (nkt > 1) gload(1);
-      __syncthreads();
-      for (int kt = 0; kt < nkt; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) stage_write(cur ^ 1);
-        if (kt + 2 < nkt) gload(kt + 2);
-        const unsigned char* As = lds + cur * STAGE;
+      auto multiply = [&](int st) {
+        const unsigned char* As = lds + st * STAGE;
         const unsigned char* Bs = As + R * ROW;
         const unsigned char* ap = As + (32 * wm + lr) * ROW + lh * 16;
         const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
@@ -599,6 +599,23 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_x3(const GemmArgs* __restric
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
           }
         }
+      };
+      gload(0, r0);
+      stage_write(0, r0);
+      if (nkt > 1) gload(1, r0);
+      if (nkt > 2) gload(2, r1);
+      __syncthreads();
+      for (int kt = 0; kt < nkt; kt += 2) {
+        // slab kt sits in stage 0, r0 holds slab kt + 1
+        if (kt + 1 < nkt) stage_write(1, r0);
+        if (kt + 3 < nkt) gload(kt + 3, r0);
+        multiply(0);
+        __syncthreads();
+        if (kt + 1 >= nkt) break;
+        // slab kt + 1 sits in stage 1, r1 holds slab kt + 2
+        if (kt + 2 < nkt) stage_write(0, r1);
+        if (kt + 4 < nkt) gload(kt + 4, r1);
+        multiply(1);
         __syncthreads();
       }
       float* ldsf = reinterpret_cast<float*>(lds4);
@@ -628,9 +645,8 @@ void free_chain_plan(ChainPlan& p) {
 
 void launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st) {
   std::vector<int> tile_start(nprob + 1, 0);
-  int t64 = 0;
-  for (int i = 0; i < nprob; i++) t64 += layers[i].rows / 64;
-  const int R = (2 * t64 <= mlp_chain_slots()) ? 32 : 64;   // enough slots for twice the workgroups: halve the tiles
+  static const int forced_r = [] { const char* e = getenv("ANI_CHAIN_WAVES"); return e ? atoi(e) : 0; }();   // experiment knob: 4 / 8
+  const int R = 64;
   for (int i = 0; i < nprob; i++) tile_start[i + 1] = tile_start[i] + layers[i].rows / R;
   const int total = tile_start[nprob];
   if (total <= 0) return;
@@ -650,11 +666,13 @@ void launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int n
     (void)hipMemcpyAsync(plan->d_desc, plan->host.data(), host.size(), hipMemcpyHostToDevice, st);
   }
   const unsigned char* d = reinterpret_cast<const unsigned char*>(plan->d_desc);
-  if (R == 32)
-    hipLaunchKernelGGL(mlp_chain_x3<1>, dim3(total), dim3(256), 0, st, reinterpret_cast<const GemmArgs*>(d),
+  // no more tiles than CUs: one eight-wave workgroup per CU; otherwise two four-wave workgroups per CU
+  const bool wide = forced_r == 8 || (forced_r != 4 && 2 * total <= mlp_chain_slots());
+  if (wide)
+    hipLaunchKernelGGL((mlp_chain_x3<2, 8>), dim3(total), dim3(512), 0, st, reinterpret_cast<const GemmArgs*>(d),
                        reinterpret_cast<const int*>(d + b0), reinterpret_cast<const int*>(d + b0 + b1), nlayers, nprob);
   else
-    hipLaunchKernelGGL(mlp_chain_x3<2>, dim3(total), dim3(256), 0, st, reinterpret_cast<const GemmArgs*>(d),
+    hipLaunchKernelGGL((mlp_chain_x3<2, 4>), dim3(total), dim3(256), 0, st, reinterpret_cast<const GemmArgs*>(d),
                        reinterpret_cast<const int*>(d + b0), reinterpret_cast<const int*>(d + b0 + b1), nlayers, nprob);
 }
 
