@@ -607,15 +607,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const
       __syncthreads();
       for (int kt = 0; kt < nkt; kt += 2) {
         // slab kt sits in stage 0, r0 holds slab kt + 1
+        multiply(0);
         if (kt + 1 < nkt) stage_write(1, r0);
         if (kt + 3 < nkt) gload(kt + 3, r0);
-        multiply(0);
         __syncthreads();
         if (kt + 1 >= nkt) break;
         // slab kt + 1 sits in stage 1, r1 holds slab kt + 2
+        multiply(1);
         if (kt + 2 < nkt) stage_write(0, r1);
         if (kt + 4 < nkt) gload(kt + 4, r1);
-        multiply(1);
         __syncthreads();
       }
       float* ldsf = reinterpret_cast<float*>(lds4);
