@@ -95,8 +95,10 @@ struct ani_handle {
 
   int max_numneigh = 0;
   DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
-  DevBuf<float4> xyzs;
-  DevBuf<int4> row_info;
+  DevBuf<float4> xyzs, cl_xyz;
+  DevBuf<int4> row_info, cl_hdr;
+  DevBuf<int> cl_j;
+  int cl_stride = 0;
   DevBuf<double> x64, f64, ev, eatom, virial_acc;
   DevBuf<double> origin;       // [3] the fp32 positions of an epoch are relative to this point (set at its first step)
   bool need_origin = true;
@@ -367,6 +369,13 @@ int rebuild(ani_handle* h, hipStream_t st) {
   HIP_TRY(h, h->gaev.reserve((size_t)std::max(h->nrows, 1) * stride));
   HIP_TRY(h, hipMemsetAsync(h->aev.p, 0, (size_t)h->nrows * stride * sizeof(float), st));  // padding rows stay zero
   HIP_TRY(h, h->e_rows.reserve((size_t)m.M * std::max(h->nrows, 1)));
+  // per-step compact neighbour lists of the fast AEV path
+  h->cl_stride = aev_compact_stride(h->ap_run, h->max_numneigh);
+  if (h->cl_stride > 0) {
+    HIP_TRY(h, h->cl_hdr.reserve((size_t)2 * std::max(h->nrows, 1)));
+    HIP_TRY(h, h->cl_xyz.reserve((size_t)std::max(h->nrows, 1) * h->cl_stride));
+    HIP_TRY(h, h->cl_j.reserve((size_t)std::max(h->nrows, 1) * h->cl_stride));
+  }
 
   // activation arena: per species, H_k (k = 1..L-1; H_{L-1} is overwritten by dE/dz_{L-1}) and the raw gradients
   // dE/dh_k (k = 1..L-2), whose celu' factor is applied by the product that consumes them
@@ -635,6 +644,8 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   a.centre_of_row = h->centre_of_row.p; a.row_info = h->row_info.p; a.nrows = h->nrows; a.aev = h->aev.p; a.gaev = h->gaev.p; a.fbuf = h->fbuf.p;
   a.virial = vflag ? h->virial_acc.p : nullptr;
   a.err_flag = h->err_flag.p;
+  a.cl_hdr = h->cl_hdr.p; a.cl_xyz = h->cl_xyz.p; a.cl_j = h->cl_j.p; a.cl_stride = h->cl_stride;
+  launch_nbr_compact(h->ap_run, a, h->max_numneigh, st);
   launch_aev_forward(h->ap_run, a, h->max_numneigh, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[1], st));
   compute_mlp(h, st);
@@ -781,7 +792,7 @@ void ani_destroy(ani_handle* h) {
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
   h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
-  h->xyzs.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->origin.release();
+  h->xyzs.release(); h->cl_xyz.release(); h->cl_hdr.release(); h->cl_j.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->origin.release();
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();

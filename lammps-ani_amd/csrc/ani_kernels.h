@@ -102,7 +102,16 @@ struct AevArgs {
   double* virial;    // backward: [kVirialSlots][9] (Hartree) partial sums, atomically added (fast path: slot = wave id
                      // mod kVirialSlots; other kernels use slot 0); may be NULL
   int* err_flag;     // set to 1 on LDS capacity overflow
+  // per-step compact neighbour lists of the fast path (nbr_compact_kernel writes, forward / backward read)
+  int4* cl_hdr;      // [2*nrows] {i (-1: skip), nrad | nang<<16 | centre species<<24, 8 x u8 angular counts} | 8 x u16 radial-only counts
+  float4* cl_xyz;    // [nrows*cl_stride] {dx, dy, dz, r}: kMaxAng slots for the neighbours inside Rca, then the radial-only ones
+  int* cl_j;         // [nrows*cl_stride] neighbour atom index
+  int cl_stride;     // entries reserved per row (kMaxAng + the kernels' radial LDS capacity)
 };
+// entries per row the compact lists need (0: the model shape takes the generic kernels, which keep no lists)
+int aev_compact_stride(const AevParams& p, int max_numneigh);
+// fast path only: screen every centre's candidate list into cl_hdr / cl_xyz / cl_j (once per step, before the forward pass)
+void launch_nbr_compact(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st);
 // max_numneigh (known at rebuild) sizes the per-centre LDS neighbour lists of the fast path
 void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st);
 // optional pairwise repulsion folded into the radial stage of the fast backward kernel (tables indexed by the compact

@@ -32,7 +32,13 @@
 namespace ani {
 
 constexpr int kWaves = 4;    // centres per workgroup: forward fast path and generic kernels
-constexpr int kWavesB = 2;   // backward fast path (its per-wave LDS slice is larger)
+constexpr int kWavesB = 4;   // backward fast path
+#ifndef ANI_BWD_MINW
+#define ANI_BWD_MINW 4
+#endif
+#ifndef ANI_FWD_MINW
+#define ANI_FWD_MINW 4
+#endif
 constexpr int kAevMax = 1024;   // LDS floats reserved for one AEV row (ANI-2x: 1008)
 constexpr int kMaxBuckets = 36; // species pairs on the fast path (S <= 8)
 
@@ -42,6 +48,17 @@ __device__ __forceinline__ void wave_sync() {
 }
 __device__ __forceinline__ int lanes_below(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+// inclusive prefix sum over the 64 lanes without LDS: four DPP shifts inside each row of 16 lanes, then the row totals
+// passed on with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
 }
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
@@ -108,31 +125,28 @@ void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_
 // fast path
 // =====================================================================================================
 struct FastLds {
-  // carved from dynamic LDS, per wave; cap = radial capacity (multiple of 64, >= max numneigh)
+  // carved from dynamic LDS, per wave
   float4* ad;     // [kMaxAng] angular neighbours dx,dy,dz,r
   float* afc;     // [kMaxAng] fc(r; Rca)
-  int* aidx;      // [kMaxAng] index into the radial list (backward)
-  float* row;     // [kAevMax] forward: AEV row; backward: dE/dAEV row
-  float* pf2;     // [64*NA]
-  float* pf1;     // [64*NZ]
+  float* row;     // [rowf] forward: AEV row; backward: dE/dAEV row
+  float* pf2;     // [64*NA] forward
+  float* pf1;     // [64*NZ] forward
   int* tb;        // [kMaxBuckets*8] bucket table
-  int* pb;        // [16] output offset of each slot group of the current chunk
   int* rstart;    // [kMaxSpecies+1]
   int* astart;    // [kMaxSpecies+1]
-  float* rr;      // [cap]
-  float* rfc;     // [cap]
-  float* rdx;     // [cap] backward
-  float* rdy;
-  float* rdz;
-  int* rj;
-  float* gd;      // [3*cap] backward
+  float* rr;      // [cap] forward: radial list r
+  float* rfc;     // [cap] forward: fc(r; Rcr)
+  int* aj;        // [kMaxAng] backward: atom index of the angular neighbours
+  float* gd;      // [3*kMaxAng] backward: dE/d(displacement) of the angular neighbours
+  float* gt;      // [3*64] backward: staging of one chunk of radial-only gradients for the force scatter
+  int* jt;        // [64]   ... and of their atom indices
 };
 
 __host__ __device__ constexpr int fast_wave_floats(int cap, bool bwd) {
-  // ad 4*kMaxAng + afc kMaxAng + aidx kMaxAng + row kAevMax + tb kMaxBuckets*8 + pb 16 + starts 2*24
+  // both: ad 4*kMaxAng + afc kMaxAng + row kAevMax + tb kMaxBuckets*8 + starts 2*24
   // forward adds the phase-1 factor buffers pf (64*12) and r, fc per radial neighbour;
-  // backward adds r, fc, dx, dy, dz, j, gd[3] per radial neighbour
-  return 6 * kMaxAng + kAevMax + kMaxBuckets * 8 + 16 + 48 + (bwd ? 9 * cap : 64 * 12 + 2 * cap);
+  // backward adds aj, gd[3] per ANGULAR neighbour and the 4*64 staging words (the radial-only neighbours never touch LDS)
+  return 5 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? 4 * kMaxAng + 256 : 64 * 12 + 2 * cap);
 }
 // same with the AEV row sized for the columns actually in use (rowf floats, multiple of 64)
 __host__ __device__ constexpr int fast_wave_floats_row(int cap, bool bwd, int rowf) {
@@ -141,55 +155,63 @@ __host__ __device__ constexpr int fast_wave_floats_row(int cap, bool bwd, int ro
 
 template <int NA, int NZ>
 __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int rowf) {
-  FastLds L;
+  FastLds L{};
   float* p = base;
   // fixed-size pieces first so that their offsets from the wave base are compile-time immediates
   L.ad = reinterpret_cast<float4*>(p); p += 4 * kMaxAng;
   L.tb = reinterpret_cast<int*>(p); p += kMaxBuckets * 8;
   L.afc = p; p += kMaxAng;
-  L.aidx = reinterpret_cast<int*>(p); p += kMaxAng;
-  L.pb = reinterpret_cast<int*>(p); p += 16;
   L.rstart = reinterpret_cast<int*>(p); p += 24;
   L.astart = reinterpret_cast<int*>(p); p += 24;
   if (!bwd) {
     L.pf2 = p; p += 64 * NA;
     L.pf1 = p; p += 64 * NZ;
+    L.row = p; p += rowf;
+    L.rr = p; p += cap;
+    L.rfc = p; p += cap;
   } else {
-    L.pf2 = L.pf1 = nullptr;
-  }
-  L.row = p; p += rowf;
-  L.rr = p; p += cap;
-  L.rfc = p; p += cap;
-  if (bwd) {
-    L.rdx = p; p += cap;
-    L.rdy = p; p += cap;
-    L.rdz = p; p += cap;
-    L.rj = reinterpret_cast<int*>(p); p += cap;
-    L.gd = p; p += 3 * cap;
-  } else {
-    L.rdx = L.rdy = L.rdz = L.gd = nullptr;
-    L.rj = nullptr;
+    L.aj = reinterpret_cast<int*>(p); p += kMaxAng;
+    L.gd = p; p += 3 * kMaxAng;
+    L.gt = p; p += 3 * 64;
+    L.jt = reinterpret_cast<int*>(p); p += 64;
+    L.row = p; p += rowf;
   }
   return L;
 }
 
-// Screen + compact the (species-sorted) neighbours of centre ii.  Lane s (< S) leaves with the number of radial /
-// angular neighbours of species s in cr / ca; group starts are written to L.rstart / L.astart.
-// info = row_info[row] = {centre atom i, first list slot, list length, centre position ii}.
-// The list is walked in super-chunks of 4 x 64 candidates: all jlist loads of a super-chunk are issued first, then
-// all position gathers, so a typical ~150-neighbour centre costs two dependent memory round trips, not six.
-// The first super-chunk arrives preloaded (Prefetched: issued one centre ahead by the persistent loop of the kernel).
-// NCH: 64-lane chunks of the list held in registers per centre (3 when no centre has more than 192 list entries,
-// e.g. water at 7.1 A: ~150; else 4) -- every chunk is 5 VGPRs in each of the two prefetch stages.
-template <int NCH>
-struct Prefetched {
-  int4 info;
-  float4 xi;
-  int jj[NCH];
-  float4 xx[NCH];
-};
-__device__ __forceinline__ int4 load_info(const AevArgs& a, int row) {
-  return row < a.nrows ? a.row_info[row] : make_int4(-1, 0, 0, -1);
+// ---- per-step compaction (its own kernel) -------------------------------------------------------------------
+// nbr_compact_kernel screens the (species-sorted) candidate list of every centre ONCE per step and leaves, per AEV row,
+//   cl_hdr[2*row + 0] = {centre atom i (-1: padding row / skipped), nrad | nang << 16 | centre species << 24,
+//                        angular neighbours of species 0..3 (u8 each), of species 4..7}
+//   cl_hdr[2*row + 1] = radial-only neighbours (Rca < r <= Rcr) per species, 8 x u16
+//   cl_xyz[row*stride + t]            , t < nang : {dx, dy, dz, r} of the neighbours inside Rca, in list (= species) order
+//   cl_xyz[row*stride + kMaxAng + u]  , u < nrad - nang : the same for the radial-only neighbours
+//   cl_j  [...]                       their atom indices (backward pass: force scatter)
+// Two append-only streams per row, so the kernel is ONE pass over the candidates with two ballots per 64 of them.
+// The forward and the backward kernel both start from these lists (coalesced 16-byte loads addressed by row: one
+// centre ahead is all the prefetch they need) instead of each walking the ~150 candidates again: the walk is a chain of
+// dependent loads (list -> positions) with little arithmetic, exactly what a small kernel at eight waves per SIMD
+// hides and a 100-170 VGPR compute kernel at three or four does not.
+// Persistent waves, software-pipelined across rows: wave w walks rows w, w + W, ...; while row c is screened, the
+// position gathers of c+1, the list loads of c+2 and the row_info of c+3 are in flight.  NCH 64-entry chunks of a list
+// are held per stage; longer lists take further super-chunks loaded in place.
+// vmcnt counts loads and stores together, in order: a wait for prefetched data that is placed AFTER a row's stores
+// waits for those stores as well (a full write round trip per row).  So every value a later row needs is waited for
+// (touch()) before the current row's stores are issued, and the stores come last in the iteration; row_info is loaded
+// through an index the compiler cannot prove uniform, or it would load + v_readfirstlane it on the spot (draining
+// every gather in flight) -- it is made scalar only when its row is started.
+constexpr int kWavesC = 4;
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ void touch(int v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void touch(float v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void touch(const float4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+__device__ __forceinline__ void touch(const int4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+__device__ __forceinline__ int4 uniform4(const int4& v) {
+  return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
+                   __builtin_amdgcn_readfirstlane(v.w));
+}
+__device__ __forceinline__ int4 load_info(const AevArgs& a, int row) {   // per-lane copy; rows past the end read the last row
+  return a.row_info[opaque(row < a.nrows ? row : a.nrows - 1)];
 }
 template <int NCH>
 __device__ __forceinline__ void load_j(const AevArgs& a, const int4 info, int lane, int (&jj)[NCH]) {
@@ -207,85 +229,225 @@ __device__ __forceinline__ void gather_x(const AevArgs& a, const int4 info, cons
   for (int c = 0; c < NCH; c++) xx[c] = a.xyzs[jj[c]];
 }
 
-template <bool BWD, int NCH>
-__device__ __forceinline__ void compact_sorted(const AevParams& p, const AevArgs& a, const Prefetched<NCH>& pf, int lane, int cap, FastLds& L,
-                                               int& nrad, int& nang, bool& over) {
-  const int4 info = pf.info;
-  const int i = info.x;
-  const int beg = info.y;
-  const int n = info.z;
-  const float4 xi = pf.xi;
-  nrad = 0;
-  nang = 0;
-  over = false;
-  int cr = 0, ca = 0;  // lane s: count of species s
-  const float half_inv_Rcr = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;  // r/(2 Rcr) revolutions
-  const float half_inv_Rca = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
-  for (int base0 = 0; base0 < n; base0 += 64 * NCH) {
-    int jj[NCH];
-    float4 xx[NCH];
-    if (base0 == 0) {
-#pragma unroll
-      for (int c = 0; c < NCH; c++) { jj[c] = pf.jj[c]; xx[c] = pf.xx[c]; }
-    } else {  // more than 64 * NCH list entries: rare, loaded in place
-#pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        const int q = base0 + 64 * c + lane;
-        jj[c] = q < n ? a.jlist[beg + q] : i;
+template <int NCH>
+__global__ __launch_bounds__(64 * kWavesC, NCH >= 4 ? 4 : 5) void nbr_compact_kernel(AevParams p, AevArgs a, int cap) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int nw = gridDim.x * kWavesC;
+  int row = blockIdx.x * kWavesC + wave;
+  if (row >= a.nrows) return;
+  const int cap2 = a.cl_stride - kMaxAng;   // room of the radial-only stream
+  int4 info = load_info(a, row), info1 = load_info(a, row + nw), info2 = load_info(a, row + 2 * nw);
+  int jj[NCH], jj1[NCH];
+  float4 xi, xx[NCH];
+  load_j(a, info, lane, jj);
+  load_j(a, info1, lane, jj1);
+  gather_x(a, info, jj, xi, xx);
+  while (row < a.nrows) {
+    // next stages
+    float4 xi1, xx1[NCH];
+    gather_x(a, info1, jj1, xi1, xx1);
+    int jj2[NCH];
+    load_j(a, info2, lane, jj2);
+    const int4 info3 = load_info(a, row + 3 * nw);
+
+    const int4 inf = uniform4(info);
+    int4* hdr = a.cl_hdr + 2 * (size_t)row;
+    const int i = inf.x, beg = inf.y, n = inf.x < 0 ? 0 : inf.z;
+    float4* oxyz = a.cl_xyz + (size_t)row * a.cl_stride;
+    int* oj = a.cl_j + (size_t)row * a.cl_stride;
+    int nA = 0, nR = 0;    // wave-uniform stream lengths
+    int ca = 0, c2 = 0;    // lane s: entries of species s in either stream
+    float4 dd[NCH];
+    int pos[NCH];          // output slot of this lane's candidate of chunk c, -1: screened out
+    auto screen = [&](int c, bool valid, const float4& xj, float4& d) -> int {
+      d.x = xj.x - xi.x; d.y = xj.y - xi.y; d.z = xj.z - xi.z;
+      d.w = __builtin_amdgcn_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+      const int sp = __float_as_int(xj.w);
+      const bool in_a = valid && d.w <= p.Rca;
+      const bool in_2 = valid && !in_a && (p.compat || d.w <= p.Rcr);
+      const unsigned long long mA = __ballot(in_a), m2 = __ballot(in_2);
+      const int pA = nA + lanes_below(mA), p2 = nR + lanes_below(m2);
+      for (int s = 0; s < p.S; s++) {
+        const int k1 = __popcll(__ballot(in_a && sp == s)), k2 = __popcll(__ballot(in_2 && sp == s));
+        if (lane == s) { ca += k1; c2 += k2; }
       }
-#pragma unroll
-      for (int c = 0; c < NCH; c++) xx[c] = a.xyzs[jj[c]];
-    }
+      nA += __popcll(mA);
+      nR += __popcll(m2);
+      return (in_a && pA < kMaxAng) ? pA : ((in_2 && p2 < cap2) ? kMaxAng + p2 : -1);
+    };
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-      const int base = base0 + 64 * c;
-      if (base < n) {  // wave-uniform
-        const bool valid = base + lane < n;
-        const int j = jj[c];
-        const float4 xj = xx[c];
-        const float dx = xj.x - xi.x, dy = xj.y - xi.y, dz = xj.z - xi.z;
-        const float r2 = dx * dx + dy * dy + dz * dz;
-        const float r = __builtin_amdgcn_sqrtf(r2);
-        const int sp = __float_as_int(xj.w);
-        const bool in_r = valid && (p.compat || r <= p.Rcr);
-        const bool in_a = valid && r <= p.Rca;
-        const unsigned long long mr = __ballot(in_r);
-        const unsigned long long ma = __ballot(in_a);
-        const int pos = nrad + lanes_below(mr);
-        if (in_r && pos < cap) {
-          L.rr[pos] = r;
-          L.rfc[pos] = 0.5f * fcos_rev(r * half_inv_Rcr) + 0.5f;
-          if (BWD) { L.rdx[pos] = dx; L.rdy[pos] = dy; L.rdz[pos] = dz; L.rj[pos] = j; }
-        }
-        const int posa = nang + lanes_below(ma);
-        if (in_a && posa < kMaxAng) {
-          L.ad[posa] = make_float4(dx, dy, dz, r);
-          L.afc[posa] = 0.5f * fcos_rev(r * half_inv_Rca) + 0.5f;
-          if (BWD) L.aidx[posa] = pos;
-        }
-        for (int s = 0; s < p.S; s++) {
-          const int c1 = __popcll(__ballot(in_r && sp == s));
-          const int c2 = __popcll(__ballot(in_a && sp == s));
-          if (lane == s) { cr += c1; ca += c2; }
-        }
-        nrad += __popcll(mr);
-        nang += __popcll(ma);
-      }
+      pos[c] = -1;
+      dd[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (64 * c < n) pos[c] = screen(c, 64 * c + lane < n, xx[c], dd[c]);   // wave-uniform test
     }
-  }
-  if (nrad > cap) { nrad = cap; over = true; }
-  if (nang > kMaxAng) { nang = kMaxAng; over = true; }
-  // exclusive prefix over species (lanes 0..S-1), S <= 16
-  int er = cr, ea = ca;
+    // everything the later rows need has now to be in registers: the stores below must not be waited for
+    touch(xi1); touch(info3);
 #pragma unroll
-  for (int off = 1; off < 16; off <<= 1) {
-    const int t1 = __shfl_up(er, off), t2 = __shfl_up(ea, off);
-    if (lane >= off) { er += t1; ea += t2; }
+    for (int c = 0; c < NCH; c++) { touch(xx1[c]); touch(jj2[c]); }
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      if (pos[c] >= 0) { oxyz[pos[c]] = dd[c]; oj[pos[c]] = jj[c]; }
+    for (int base0 = 64 * NCH; base0 < n; base0 += 64) {   // more than 64 * NCH list entries: rare, loaded in place
+      const int q = base0 + lane;
+      const int j = q < n ? a.jlist[beg + q] : i;
+      const float4 xj = a.xyzs[j];
+      float4 d;
+      const int ps = screen(0, q < n, xj, d);
+      if (ps >= 0) { oxyz[ps] = d; oj[ps] = j; }
+    }
+    // capacity of the consumers' LDS lists: never a silent truncation -- the row is skipped and the error flag raised
+    const bool over = nA > kMaxAng || nR > cap2 || nA + nR > cap;
+    if (lane < 8) {
+      reinterpret_cast<unsigned char*>(hdr)[8 + lane] = (unsigned char)ca;
+      reinterpret_cast<unsigned short*>(hdr)[8 + lane] = (unsigned short)c2;
+    }
+    if (lane == 0) {
+      reinterpret_cast<int*>(hdr)[0] = (over || inf.x < 0) ? -1 : i;
+      reinterpret_cast<int*>(hdr)[1] = (nA + nR) | (nA << 16) | (__float_as_int(xi.w) << 24);
+      if (over) atomicOr(a.err_flag, 1);
+    }
+    info = info1; info1 = info2; info2 = info3;
+    xi = xi1;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) { jj[c] = jj1[c]; xx[c] = xx1[c]; jj1[c] = jj2[c]; }
+    row += nw;
   }
-  if (lane <= p.S) {
-    // lane s holds inclusive sums; start[s] = incl - count ; start[S] = total
-    if (lane < p.S) { L.rstart[lane] = min(er - cr, cap); L.astart[lane] = min(ea - ca, kMaxAng); }
-    else { L.rstart[lane] = nrad; L.astart[lane] = nang; }
+}
+
+// What the forward / backward kernels prefetch for a centre, all addressed by its row alone (no dependent loads): the
+// header (per-lane copies; made scalar when the centre is started), slots 0..63 of the angular region, the first NCH
+// 64-entry chunks of the radial-only region (entries past the counts are stale memory, masked by the consumer) and,
+// for the backward pass, the atom indices and the dE/dAEV row.  Issued one centre ahead; the consumer touch()es all of
+// it before it issues its own stores / atomics (vmcnt is in-order: see nbr_compact_kernel).
+typedef int hdr_t __attribute__((ext_vector_type(8)));
+template <int NCH, bool BWD, int GR>
+struct Prefetched {
+  int4 h0, h1;
+  float4 xa, xr[NCH];
+  int ja, jr[BWD ? NCH : 1];
+  float4 grow[BWD ? GR : 1];
+};
+template <int NCH, bool BWD, int GR>
+__device__ __forceinline__ void issue_prefetch(const AevParams& p, const AevArgs& a, int row, int lane, Prefetched<NCH, BWD, GR>& pf) {
+  const int rc = opaque(row < a.nrows ? row : a.nrows - 1);
+  const int4* hp = a.cl_hdr + 2 * (size_t)rc;
+  pf.h0 = hp[0];
+  pf.h1 = hp[1];
+  const float4* px = a.cl_xyz + (size_t)rc * a.cl_stride;
+  const int* pj = a.cl_j + (size_t)rc * a.cl_stride;
+  pf.xa = px[lane];
+  if constexpr (BWD) pf.ja = pj[lane];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    pf.xr[c] = px[kMaxAng + 64 * c + lane];
+    if constexpr (BWD) pf.jr[c] = pj[kMaxAng + 64 * c + lane];
+  }
+  if constexpr (BWD) {
+    const int n4 = p.aev_stride >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(a.gaev + (size_t)rc * p.aev_stride);
+#pragma unroll
+    for (int c = 0; c < GR; c++) pf.grow[c] = g4[min(lane + 64 * c, n4 - 1)];
+  }
+}
+template <int NCH, bool BWD, int GR>
+__device__ __forceinline__ void touch_prefetch(const Prefetched<NCH, BWD, GR>& pf) {
+  touch(pf.h0); touch(pf.h1); touch(pf.xa);
+  if constexpr (BWD) touch(pf.ja);
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    touch(pf.xr[c]);
+    if constexpr (BWD) touch(pf.jr[c]);
+  }
+  if constexpr (BWD) {
+#pragma unroll
+    for (int c = 0; c < GR; c++) touch(pf.grow[c]);
+  }
+}
+template <int NCH, bool BWD, int GR>
+__device__ __forceinline__ hdr_t scalar_header(const AevArgs& a, int row, const Prefetched<NCH, BWD, GR>& pf) {
+  hdr_t h;
+  h[0] = row < a.nrows ? __builtin_amdgcn_readfirstlane(pf.h0.x) : -1;
+  h[1] = __builtin_amdgcn_readfirstlane(pf.h0.y); h[2] = __builtin_amdgcn_readfirstlane(pf.h0.z);
+  h[3] = __builtin_amdgcn_readfirstlane(pf.h0.w); h[4] = __builtin_amdgcn_readfirstlane(pf.h1.x);
+  h[5] = __builtin_amdgcn_readfirstlane(pf.h1.y); h[6] = __builtin_amdgcn_readfirstlane(pf.h1.z);
+  h[7] = __builtin_amdgcn_readfirstlane(pf.h1.w);
+  return h;
+}
+__device__ __forceinline__ int hdr_nrad(const hdr_t& h) { return h[0] < 0 ? 0 : (h[1] & 0xffff); }
+__device__ __forceinline__ int hdr_nang(const hdr_t& h) { return h[0] < 0 ? 0 : ((h[1] >> 16) & 0xff); }
+__device__ __forceinline__ int hdr_species(const hdr_t& h) { return (h[1] >> 24) & 0xf; }
+
+// scalar bookkeeping of a centre's compact list: starts of species k in the angular stream (as), in the radial-only
+// stream (r2) and in the species-grouped radial order (rs); entry 8 holds the totals
+struct Groups { int as[9], r2[9], rs[9]; };
+__device__ __forceinline__ Groups unpack_groups(const hdr_t& h) {
+  Groups g;
+  g.as[0] = g.r2[0] = g.rs[0] = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int cak = (h[2 + (k >> 2)] >> (8 * (k & 3))) & 0xff, c2k = (h[4 + (k >> 1)] >> (16 * (k & 1))) & 0xffff;
+    g.as[k + 1] = g.as[k] + cak;
+    g.r2[k + 1] = g.r2[k] + c2k;
+    g.rs[k + 1] = g.rs[k] + cak + c2k;
+  }
+  return g;
+}
+__device__ __forceinline__ void store_starts(const AevParams& p, const Groups& g, int nrad, int nang, int lane, FastLds& L) {
+  int vr = nrad, va = nang;   // entries S.. of the start tables hold the totals
+#pragma unroll
+  for (int k = 7; k >= 0; k--)
+    if (lane == k && k < p.S) { vr = g.rs[k]; va = g.as[k]; }
+  if (lane <= p.S) { L.rstart[lane] = vr; L.astart[lane] = va; }
+}
+
+// Forward: fill the wave's LDS lists from the prefetched compact list: the radial list {r, fc} grouped by species (inside
+// a group the angular neighbours first), the angular list (the angular region as it stands, already in species order),
+// group starts in L.rstart / L.astart.  All per-species bookkeeping is scalar.
+template <int NCH>
+__device__ __forceinline__ void unpack_lists(const AevParams& p, const AevArgs& a, int row, const hdr_t& h,
+                                             const Prefetched<NCH, false, 1>& pf, int lane, FastLds& L, int& nrad, int& nang) {
+  nrad = hdr_nrad(h);
+  nang = hdr_nang(h);
+  const Groups g = unpack_groups(h);
+  store_starts(p, g, nrad, nang, lane, L);
+  const float half_inv_Rcr = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;  // r/(2 Rcr) revolutions
+  const float half_inv_Rca = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
+  const float4* __restrict__ px = a.cl_xyz + (size_t)row * a.cl_stride;
+  // w-th entry of the angular (ang) or the radial-only stream -> position in the LDS radial list
+  auto place = [&](bool ang, int w, const float4& v) {
+    int pos = w;   // species 0: the radial-only entries follow its as[1] angular ones
+    int lead = g.as[1];
+#pragma unroll
+    for (int k = 1; k < 8; k++)
+      if (k < p.S) {
+        const int st = ang ? g.as[k] : g.r2[k];
+        if (w >= st) { pos = g.rs[k] + (w - st); lead = g.as[k + 1] - g.as[k]; }
+      }
+    if (!ang) pos += lead;
+    L.rr[pos] = v.w;
+    L.rfc[pos] = 0.5f * fcos_rev(v.w * half_inv_Rcr) + 0.5f;
+    if (ang) {
+      L.ad[w] = v;
+      L.afc[w] = 0.5f * fcos_rev(v.w * half_inv_Rca) + 0.5f;
+    }
+  };
+  for (int base = 0; base < nang; base += 64) {
+    const int t = base + lane;
+    if (t < nang) place(true, t, base == 0 ? pf.xa : px[t]);   // more than 64 angular neighbours: loaded in place
+  }
+  const int nr2 = nrad - nang;
+  for (int base = 0; base < nr2; base += 64) {
+    const int c = base >> 6, t = base + lane;
+    float4 v = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (c < NCH) {
+#pragma unroll
+      for (int k = 0; k < NCH; k++)
+        if (c == k) v = pf.xr[k];
+    } else if (t < nr2) {
+      v = px[kMaxAng + t];
+    }
+    if (t < nr2) place(false, t, v);
   }
 }
 
@@ -305,12 +467,7 @@ __device__ __forceinline__ int build_bucket_table(const AevParams& p, int lane, 
     np = (s1 == s2) ? n1 * (n1 - 1) / 2 : n1 * n2;
   }
   const int npad = (np + Q - 1) / Q * Q;
-  int incl = npad;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
-  }
+  const int incl = wave_incl_scan(npad);
   const unsigned long long m = __ballot(np > 0);
   if (np > 0) {
     int* e = L.tb + 8 * lanes_below(m);
@@ -318,7 +475,7 @@ __device__ __forceinline__ int build_bucket_table(const AevParams& p, int lane, 
     e[5] = p.radial_len + lane * (NA * NZ); e[6] = (s1 == s2) ? 1 : 0; e[7] = np;
   }
   nbk = __popcll(m);
-  return __shfl(incl, 63);
+  return __builtin_amdgcn_readlane(incl, 63);
 }
 
 // lane -> its pair of the padded stream.  valid = false for padding slots (indices then point at neighbour 0 of
@@ -415,12 +572,7 @@ __device__ __forceinline__ int build_row_table(const AevParams& p, int lane, Fas
       nrow = nrows * ncb;
     }
   }
-  int incl = nrow;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
-  }
+  const int incl = wave_incl_scan(nrow);
   const unsigned long long m = __ballot(nrow > 0);
   if (nrow > 0) {
     int* e = L.tb + 8 * lanes_below(m);
@@ -428,18 +580,16 @@ __device__ __forceinline__ int build_row_table(const AevParams& p, int lane, Fas
     e[5] = p.radial_len + lane * (NA * NZ); e[6] = tri; e[7] = ncb;
   }
   nbk = __popcll(m);
-  return __shfl(incl, 63);
+  return __builtin_amdgcn_readlane(incl, 63);
 }
 
-template <int NA, int NZ, int NCH>
-__device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row,
-                                               const Prefetched<NCH>& pf, int lane) {
+template <int NA, int NZ, int NCH, typename Hook>
+__device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
+                                               const Prefetched<NCH, false, 1>& pf, int lane, Hook&& before_stores) {
   constexpr int NR = 16, Q = 64 / NA;
   for (int e = lane; e < (p.aev_stride >> 2); e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
   int nrad, nang;
-  bool over;
-  compact_sorted<false, NCH>(p, a, pf, lane, cap, L, nrad, nang, over);
-  if (over && lane == 0) atomicOr(a.err_flag, 1);
+  unpack_lists<NCH>(p, a, row, h, pf, lane, L, nrad, nang);
   wave_sync();
 
   // ---- radial: per species group, lanes = (slot q, shift k) ----
@@ -451,12 +601,19 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
     for (int s = 0; s < p.S; s++) {
       const int b0 = L.rstart[s], b1 = L.rstart[s + 1];
       if (b1 <= b0) continue;
-      float acc = 0.f;
-      for (int t = b0 + q; t < b1; t += 4) {
+      float acc = 0.f, acc2 = 0.f;
+      int t = b0 + q;
+      for (; t + 4 < b1; t += 8) {   // two neighbours per trip: their LDS reads and exponentials overlap
+        const float r0 = L.rr[t], r1 = L.rr[t + 4], f0 = L.rfc[t], f1 = L.rfc[t + 4];
+        const float d0 = r0 - shf, d1 = r1 - shf;
+        acc = fmaf(fexp2(c * d0 * d0), f0, acc);
+        acc2 = fmaf(fexp2(c * d1 * d1), f1, acc2);
+      }
+      if (t < b1) {
         const float dr = L.rr[t] - shf;
         acc = fmaf(fexp2(c * dr * dr), L.rfc[t], acc);
       }
-      acc = xor_sum<32>(xor_sum<16>(acc));   // row / half-wave swaps, no LDS round trip
+      acc = xor_sum<32>(xor_sum<16>(acc + acc2));   // row / half-wave swaps, no LDS round trip
       if (q == 0) L.row[s * NR + k] = 0.25f * acc;
     }
   }
@@ -498,8 +655,9 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
   for (int base = 0; base < total; base += 64) {
 #endif
     // phase 1: lane = pair
+    int outoff;
     {
-      int ia, ib, outoff;
+      int ia, ib;
       bool valid;
       stream_pair(L, nbk, base + lane, ia, ib, outoff, valid);
       const float4 A = L.ad[ia], B = L.ad[ib];
@@ -527,21 +685,36 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
 #pragma unroll
       for (int s = 0; s < NA; s += 4)
         *reinterpret_cast<float4*>(L.pf2 + lane * NA + s) = make_float4(t2[s], t2[s + 1], t2[s + 2], t2[s + 3]);
-      if ((lane % Q) == 0) L.pb[lane / Q] = outoff;
     }
     wave_sync();
-    // phase 2: lane = (slot lq, shift la); group g covers slots g*Q .. g*Q+Q-1, all of one bucket
+    // phase 2: lane = (slot lq, shift la); group g covers slots g*Q .. g*Q+Q-1, all of one bucket (its output offset is
+    // read from the register of the group's first pair: no LDS round trip in front of the flush test).  The factors of
+    // group g+1 are requested before group g is accumulated.
     const int ngroups = min(NA, (total - base + Q - 1) / Q);
-    for (int g = 0; g < ngroups; g++) {
-      const int off = __builtin_amdgcn_readfirstlane(L.pb[g]);
-      if (off != cur_off) { flush(); cur_off = off; }
-      const int slot = g * Q + lq;
-      const float f2 = L.pf2[slot * NA + la];
+    float f2n = L.pf2[lq * NA + la];
+    float4 qn[NZ / 4];
 #pragma unroll
-      for (int z = 0; z < NZ; z += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(L.pf1 + slot * NZ + z);
-        acc[z] = fmaf(f2, q.x, acc[z]); acc[z + 1] = fmaf(f2, q.y, acc[z + 1]);
-        acc[z + 2] = fmaf(f2, q.z, acc[z + 2]); acc[z + 3] = fmaf(f2, q.w, acc[z + 3]);
+    for (int z4 = 0; z4 < NZ / 4; z4++) qn[z4] = *reinterpret_cast<const float4*>(L.pf1 + lq * NZ + 4 * z4);
+#pragma unroll
+    for (int g = 0; g < NA; g++) {
+      if (g < ngroups) {   // wave-uniform
+        const float f2 = f2n;
+        float4 q[NZ / 4];
+#pragma unroll
+        for (int z4 = 0; z4 < NZ / 4; z4++) q[z4] = qn[z4];
+        if (g + 1 < NA && g + 1 < ngroups) {
+          const int slot = (g + 1) * Q + lq;
+          f2n = L.pf2[slot * NA + la];
+#pragma unroll
+          for (int z4 = 0; z4 < NZ / 4; z4++) qn[z4] = *reinterpret_cast<const float4*>(L.pf1 + slot * NZ + 4 * z4);
+        }
+        const int off = __builtin_amdgcn_readlane(outoff, g * Q);
+        if (off != cur_off) { flush(); cur_off = off; }
+#pragma unroll
+        for (int z4 = 0; z4 < NZ / 4; z4++) {
+          acc[4 * z4] = fmaf(f2, q[z4].x, acc[4 * z4]); acc[4 * z4 + 1] = fmaf(f2, q[z4].y, acc[4 * z4 + 1]);
+          acc[4 * z4 + 2] = fmaf(f2, q[z4].z, acc[4 * z4 + 2]); acc[4 * z4 + 3] = fmaf(f2, q[z4].w, acc[4 * z4 + 3]);
+        }
       }
     }
     wave_sync();
@@ -549,92 +722,142 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
   flush();
   wave_sync();
 
+  before_stores();   // the next centre's prefetch is secured before this centre's stores enter the vmcnt queue
   float4* dst = reinterpret_cast<float4*>(a.aev + (long long)row * p.aev_stride);
   const int n4 = p.aev_stride >> 2;
   for (int e = lane; e < n4; e += 64) dst[e] = reinterpret_cast<const float4*>(L.row)[e];
   wave_sync();  // the LDS slice is reused by this wave's next centre
 }
 
-// Persistent waves: wave w handles rows w, w + W, w + 2W, ...  The three dependent loads of a centre
-// (row_info -> jlist -> positions) are software-pipelined across centres: while centre c is being processed, the
-// position gathers of c+1, the list loads of c+2 and the row_info of c+3 are in flight.
-#define ANI_PERSISTENT_LOOP(KW, NCH, PRE_CALL, CENTRE_CALL)                                                  \
+// Persistent waves: wave w handles rows w, w + W, w + 2W, ...; the inputs of centre c+1 are requested when centre c is
+// started and secured (touch_prefetch + the scalar copy of its header) right before centre c issues its stores /
+// atomics.  Two prefetch stages used alternately (the loop body is written out twice): a `cur = nxt` copy lets the
+// compiler move parts of it up to the loads, which then wait for them on the spot.
+#define ANI_PERSISTENT_LOOP(KW, NCH, BWD, GR, CENTRE)                                                      \
   const int nw = gridDim.x * KW;                                                                          \
   int row = blockIdx.x * KW + wave;                                                                       \
-  Prefetched<NCH> cur, nxt;                                                                               \
-  cur.info = load_info(a, row);                                                                           \
-  nxt.info = load_info(a, row + nw);                                                                      \
-  int4 info2 = load_info(a, row + 2 * nw);                                                                \
-  load_j(a, cur.info, lane, cur.jj);                                                                      \
-  load_j(a, nxt.info, lane, nxt.jj);                                                                      \
-  gather_x(a, cur.info, cur.jj, cur.xi, cur.xx);                                                          \
-  while (row < a.nrows) {                                                                                 \
-    PRE_CALL;                                                                                             \
-    gather_x(a, nxt.info, nxt.jj, nxt.xi, nxt.xx);                                                        \
-    int jj2[NCH];                                                                                         \
-    load_j(a, info2, lane, jj2);                                                                          \
-    const int4 info3 = load_info(a, row + 3 * nw);                                                        \
-    if (cur.info.x >= 0) { CENTRE_CALL; }                                                                 \
-    cur = nxt;                                                                                            \
-    nxt.info = info2;                                                                                     \
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) nxt.jj[c] = jj2[c];                                   \
-    info2 = info3;                                                                                        \
-    row += nw;                                                                                            \
+  if (row >= a.nrows) return;                                                                             \
+  Prefetched<NCH, BWD, GR> sA, sB;                                                                        \
+  hdr_t hA, hB;                                                                                           \
+  issue_prefetch(p, a, row, lane, sA);                                                                    \
+  touch_prefetch(sA);                                                                                     \
+  hA = scalar_header(a, row, sA);                                                                         \
+  while (true) {                                                                                          \
+    {                                                                                                     \
+      issue_prefetch(p, a, row + nw, lane, sB);                                                           \
+      auto secure = [&]() { touch_prefetch(sB); hB = scalar_header(a, row + nw, sB); };                  \
+      const hdr_t& hc = hA;                                                                               \
+      const Prefetched<NCH, BWD, GR>& cur = sA;                                                           \
+      if (hc[0] >= 0) { CENTRE; } else { secure(); }                                                      \
+      row += nw;                                                                                          \
+      if (row >= a.nrows) break;                                                                          \
+    }                                                                                                     \
+    {                                                                                                     \
+      issue_prefetch(p, a, row + nw, lane, sA);                                                           \
+      auto secure = [&]() { touch_prefetch(sA); hA = scalar_header(a, row + nw, sA); };                  \
+      const hdr_t& hc = hB;                                                                               \
+      const Prefetched<NCH, BWD, GR>& cur = sB;                                                           \
+      if (hc[0] >= 0) { CENTRE; } else { secure(); }                                                      \
+      row += nw;                                                                                          \
+      if (row >= a.nrows) break;                                                                          \
+    }                                                                                                     \
   }
 
 template <int NA, int NZ, int NCH>
-__global__ __launch_bounds__(64 * kWaves) void aev_forward_fast(AevParams p, AevArgs a, int cap, int rowf) {
+__global__ __launch_bounds__(64 * kWaves, ANI_FWD_MINW) void aev_forward_fast(AevParams p, AevArgs a, int cap, int rowf) {
   extern __shared__ float4 smem4[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, false, rowf), cap, false, rowf);
-  ANI_PERSISTENT_LOOP(kWaves, NCH, (void)0, (forward_centre<NA, NZ, NCH>(p, a, cap, L, row, cur, lane)))
+  ANI_PERSISTENT_LOOP(kWaves, NCH, false, 1, (forward_centre<NA, NZ, NCH>(p, a, L, row, hc, cur, lane, secure)))
 }
 
-template <int NA, int NZ, int NCH, int GR>
-__device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, int cap, FastLds& L, int row,
-                                                const Prefetched<NCH>& pf, const float4 (&grow)[GR], int lane, float (&wv)[9],
-                                                const RepTab& rep, float& er) {
+// coalesced force scatter of `cnt` neighbours whose gradients sit in LDS as g[3*q + k] with atom indices jx[q]:
+// lane = (list slot, component), so the three adds of one atom (one float4 of fbuf) leave from adjacent lanes of ONE
+// instruction.  Global float atomics execute at the memory side as 64-byte requests (MI355X_MICROARCH.md): three
+// separate instructions per neighbour were three requests, this is one, and atoms adjacent both in memory and in the
+// (spatially ordered) list share requests too.
+__device__ __forceinline__ void scatter_neighbours(const AevArgs& a, const float* g, const int* jx, int cnt, int lane) {
+#ifndef ABL_NO_GATOM
+  for (int base = 0; base < cnt; base += 16) {
+    const int q = base + (lane >> 2), k = lane & 3;
+    if (q < cnt && k < 3) atomicAdd(&a.fbuf[4 * jx[q] + k], -g[3 * q + k]);
+  }
+#endif
+}
+
+template <int NA, int NZ, int NCH, int GR, bool VIR, typename Hook>
+__device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
+                                                const Prefetched<NCH, true, GR>& pf, int lane, float (&wv)[9],
+                                                const RepTab& rep, float& er, Hook&& before_final_scatter) {
   constexpr int NR = 16;
-  const int4 info = pf.info;
+  const int centre = h[0];
 #pragma unroll
   for (int c = 0; c < GR; c++)
-    if (lane + 64 * c < (p.aev_stride >> 2)) reinterpret_cast<float4*>(L.row)[lane + 64 * c] = grow[c];
-  int nrad, nang;
-  bool over;
-  compact_sorted<true, NCH>(p, a, pf, lane, cap, L, nrad, nang, over);
-  if (over && lane == 0) atomicOr(a.err_flag, 1);
-  wave_sync();
+    if (lane + 64 * c < (p.aev_stride >> 2)) reinterpret_cast<float4*>(L.row)[lane + 64 * c] = pf.grow[c];
+  const int nrad = hdr_nrad(h), nang = hdr_nang(h);
+  const Groups grp = unpack_groups(h);
+  store_starts(p, grp, nrad, nang, lane, L);
+  wave_sync();   // the dE/dAEV row is read below
 
-  // ---- radial: one lane per neighbour (species from the group boundaries) ----
-  {
-    const float cR = -p.EtaR * kLog2e;
-    const float rev = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;
-#ifdef ABL_NO_RAD
-    for (int t = lane; t < nrad; t += 64) { L.gd[3 * t] = 0.f; L.gd[3 * t + 1] = 0.f; L.gd[3 * t + 2] = 0.f; }
-    for (int t = lane; t < 0; t += 64) {
-#else
-    for (int t = lane; t < nrad; t += 64) {
-#endif
+  // ---- radial stage, one lane per neighbour, straight from the prefetched registers.  A radial-only neighbour
+  // (Rca < r <= Rcr) is finished here: its gradient goes to the centre's sums and, through a 64-slot staging buffer,
+  // to the force scatter.  A neighbour inside Rca parks its displacement, atom index and radial gradient in LDS, where
+  // the angular stage adds to it. ----
+  float fx = 0.f, fy = 0.f, fz = 0.f;   // this lane's share of sum_j g_j (force on the centre)
+  const float cR = -p.EtaR * kLog2e;
+  const float rev = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;
+  const float revA = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
+  const float4* __restrict__ px = a.cl_xyz + (size_t)row * a.cl_stride;
+  const int* __restrict__ pj = a.cl_j + (size_t)row * a.cl_stride;
+  // chunks: the angular region first (ceil(nang / 64) of them), then the radial-only region
+  const int nr2 = nrad - nang, cha = (nang + 63) >> 6, chr = (nr2 + 63) >> 6;
+  for (int ch = 0; ch < cha + chr; ch++) {
+    const bool ang = ch < cha;
+    const int c = ang ? ch : ch - cha, w = 64 * c + lane;   // w: index in its stream
+    const bool live = w < (ang ? nang : nr2);
+    float4 v = make_float4(0.f, 0.f, 0.f, 1.f);
+    int j = 0;
+    if (ang && c == 0) { v = pf.xa; j = pf.ja; }
+    else if (!ang && c < NCH) {
+#pragma unroll
+      for (int k = 0; k < NCH; k++)
+        if (c == k) { v = pf.xr[k]; j = pf.jr[k]; }
+    } else if (live) {  // lists longer than the prefetched chunks: loaded in place
+      v = px[(ang ? 0 : kMaxAng) + w];
+      j = pj[(ang ? 0 : kMaxAng) + w];
+    }
+    const int t = w;   // angular neighbours: index of the LDS accumulators
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+#ifndef ABL_NO_RAD
+    if (live) {
       int s = 0;
-      for (int k = 1; k < p.S; k++) s += (t >= L.rstart[k]) ? 1 : 0;
-      const float* gg = L.row + s * NR;
-      const float r = L.rr[t], fc = L.rfc[t];
+#pragma unroll
+      for (int k = 1; k < 8; k++)
+        if (k < p.S) s += (w >= (ang ? grp.as[k] : grp.r2[k])) ? 1 : 0;
+      const float4* gg4 = reinterpret_cast<const float4*>(L.row + s * NR);
+      const float r = v.w;
+      const float fc = 0.5f * fcos_rev(r * rev) + 0.5f;
       const float dfc = -0.5f * p.pi_over_Rcr * fsin_rev(r * rev);
       float dEdr = 0.f;
 #pragma unroll
-      for (int k = 0; k < NR; k++) {
-        const float dr = r - p.ShfR[k];
-        const float e = fexp2(cR * dr * dr);
-        dEdr = fmaf(gg[k] * e, fmaf(-2.f * p.EtaR * dr, fc, dfc), dEdr);
+      for (int k4 = 0; k4 < NR / 4; k4++) {
+        const float4 gv = gg4[k4];
+        const float gk[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const float dr = r - p.ShfR[4 * k4 + kk];
+          const float e = fexp2(cR * dr * dr);
+          dEdr = fmaf(gk[kk] * e, fmaf(-2.f * p.EtaR * dr, fc, dfc), dEdr);
+        }
       }
       const float sc = 0.25f * dEdr * frcp(r);
-      float gx = sc * L.rdx[t], gy = sc * L.rdy[t], gz = sc * L.rdz[t];
+      gx = sc * v.x; gy = sc * v.y; gz = sc * v.z;
       if (rep.on && r < rep.cutoff) {
         // pairwise repulsion (ani_kernels_rep.hip has the formulas): half of e(r) per list entry.  The pair function in
         // fp32 like the rest of this precision mode, but its argument from the fp64 positions: the wall is steep
-        const int ti = 8 * __float_as_int(pf.xi.w) + s;
-        const double* xj = rep.x64 + 3 * (long long)L.rj[t];
-        const double* xc = rep.x64 + 3 * (long long)info.x;
+        const int ti = 8 * hdr_species(h) + s;
+        const double* xj = rep.x64 + 3 * (long long)j;
+        const double* xc = rep.x64 + 3 * (long long)centre;
         const double ddx = xj[0] - xc[0], ddy = xj[1] - xc[1], ddz = xj[2] - xc[2];
         const double r64 = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
         const float rr = (float)r64;
@@ -652,9 +875,30 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
           gx += sr * (float)(ddx * inv); gy += sr * (float)(ddy * inv); gz += sr * (float)(ddz * inv);
         }
       }
-      L.gd[3 * t + 0] = gx;
-      L.gd[3 * t + 1] = gy;
-      L.gd[3 * t + 2] = gz;
+    }
+#endif
+    if (live && ang) {
+      L.ad[t] = v;
+      L.afc[t] = 0.5f * fcos_rev(v.w * revA) + 0.5f;
+      L.aj[t] = j;
+      L.gd[3 * t] = gx; L.gd[3 * t + 1] = gy; L.gd[3 * t + 2] = gz;
+    }
+    // radial-only neighbours: finished here
+    if (!ang) {   // wave-uniform
+      const int lo = 0, hi = min(nr2 - 64 * c, 64);
+      if (live) {
+        fx += gx; fy += gy; fz += gz;
+        if constexpr (VIR) {
+          wv[0] += gx * v.x; wv[1] += gx * v.y; wv[2] += gx * v.z;
+          wv[3] += gy * v.x; wv[4] += gy * v.y; wv[5] += gy * v.z;
+          wv[6] += gz * v.x; wv[7] += gz * v.y; wv[8] += gz * v.z;
+        }
+        L.gt[3 * (lane - lo)] = gx; L.gt[3 * (lane - lo) + 1] = gy; L.gt[3 * (lane - lo) + 2] = gz;
+        L.jt[lane - lo] = j;
+      }
+      wave_sync();
+      scatter_neighbours(a, L.gt, L.jt, hi - lo, lane);
+      wave_sync();   // the staging buffer is reused by the next chunk
     }
   }
   int nbk;
@@ -663,7 +907,6 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
 
   // ---- angular: lane = pair; 4 rows of the stream per step (see build_row_table) ----
   const float cA = -p.EtaA * kLog2e;
-  const float revA = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
 #ifdef ABL_NO_ANG
   for (int R0 = 0; R0 < 0; R0 += 4) {
 #else
@@ -739,9 +982,8 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     const float vb[3] = {cc * A.x + tb * B.x, cc * A.y + tb * B.y, cc * A.z + tb * B.z};  // d/d(neighbour ib)
 #ifndef ABL_NO_LATOM
     // column neighbour: one LDS add per lane and component
-    if (valid) {
-      const int qb = L.aidx[ib];
-      TILE_ADD(&L.gd[3 * qb], vb[0]); TILE_ADD(&L.gd[3 * qb + 1], vb[1]); TILE_ADD(&L.gd[3 * qb + 2], vb[2]);
+    if (valid) {   // angular list index = index of the LDS accumulators
+      TILE_ADD(&L.gd[3 * ib], vb[0]); TILE_ADD(&L.gd[3 * ib + 1], vb[1]); TILE_ADD(&L.gd[3 * ib + 2], vb[2]);
     }
     // row neighbour(s): sums over the 16 lanes of the row, [0..2] for the pairs whose ia is r (all pairs of a
     // rectangular bucket, the above-diagonal ones of a folded triangle), [3..5] for those whose ia is nn-1-r
@@ -752,11 +994,11 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     for (int k = 0; k < 6; k++) rw[k] = xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(rw[k]))));
     if ((lane & 15) == 0 && row_ok) {
       if (r < e0.z) {
-        const int q = L.aidx[e0.y + r];
+        const int q = e0.y + r;
         TILE_ADD(&L.gd[3 * q], rw[0]); TILE_ADD(&L.gd[3 * q + 1], rw[1]); TILE_ADD(&L.gd[3 * q + 2], rw[2]);
       }
       if (tri && nn - 1 - r < e0.z) {
-        const int q = L.aidx[e0.y + nn - 1 - r];
+        const int q = e0.y + nn - 1 - r;
         TILE_ADD(&L.gd[3 * q], rw[3]); TILE_ADD(&L.gd[3 * q + 1], rw[4]); TILE_ADD(&L.gd[3 * q + 2], rw[5]);
       }
     }
@@ -766,70 +1008,53 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   }
   wave_sync();
 
-  // ---- scatter: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d ----
-  float fx = 0.f, fy = 0.f, fz = 0.f;
-  for (int q = lane; q < nrad; q += 64) {
+  // ---- the angular neighbours: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d ----
+  before_final_scatter();   // the next centre's prefetch is secured before these atomics enter the vmcnt queue
+  for (int q = lane; q < nang; q += 64) {
     const float gx = L.gd[3 * q], gy = L.gd[3 * q + 1], gz = L.gd[3 * q + 2];
     fx += gx; fy += gy; fz += gz;
-    // virial: per-lane partial sums kept across all the centres of this wave; the nine totals are reduced over the
-    // lanes and added to the global accumulator ONCE per wave at the end of the kernel (nine double atomics per centre
-    // on nine addresses serialise at the memory side: 10 ms per step at 100 000 centres).  Accumulated whether or not
-    // the caller wants the virial: 12 instructions per centre, and a test here makes the compiler clone the whole
-    // centre loop into a slower second version.
-    const float dx = L.rdx[q], dy = L.rdy[q], dz = L.rdz[q];
-    wv[0] += gx * dx; wv[1] += gx * dy; wv[2] += gx * dz;
-    wv[3] += gy * dx; wv[4] += gy * dy; wv[5] += gy * dz;
-    wv[6] += gz * dx; wv[7] += gz * dy; wv[8] += gz * dz;
+    if constexpr (VIR) {
+      // virial: per-lane partial sums kept across all the centres of this wave; the nine totals are reduced over the
+      // lanes and added to the global accumulator ONCE per wave at the end of the kernel (nine double atomics per centre
+      // on nine addresses serialise at the memory side: 10 ms per step at 100 000 centres)
+      const float4 d = L.ad[q];
+      wv[0] += gx * d.x; wv[1] += gx * d.y; wv[2] += gx * d.z;
+      wv[3] += gy * d.x; wv[4] += gy * d.y; wv[5] += gy * d.z;
+      wv[6] += gz * d.x; wv[7] += gz * d.y; wv[8] += gz * d.z;
+    }
   }
+  scatter_neighbours(a, L.gd, L.aj, nang, lane);
   fx = xor_sum<32>(xor_sum<16>(xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(fx))))));
   fy = xor_sum<32>(xor_sum<16>(xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(fy))))));
   fz = xor_sum<32>(xor_sum<16>(xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(fz))))));
-  const int i = info.x;
-#ifndef ABL_NO_GATOM
-  // neighbour forces, lane = (list slot, component): global float atomics execute at the memory side as 64-byte
-  // requests, so the three components of one atom (one float4 of fbuf) go out from adjacent lanes of ONE instruction
-  // and share a request -- as do atoms that are adjacent both in memory and in the (spatially ordered) list
-  for (int base = 0; base < nrad; base += 16) {
-    const int q = base + (lane >> 2), k = lane & 3;
-    if (q < nrad && k < 3) atomicAdd(&a.fbuf[4 * L.rj[q] + k], -L.gd[3 * q + k]);
-  }
-#endif
-  if (lane < 3) atomicAdd(&a.fbuf[4 * i + lane], lane == 0 ? fx : (lane == 1 ? fy : fz));
+  if (lane < 3) atomicAdd(&a.fbuf[4 * centre + lane], lane == 0 ? fx : (lane == 1 ? fy : fz));
   wave_sync();  // the LDS slice is reused by this wave's next centre
 }
 
-template <int NA, int NZ, int NCH, int GR>
-__global__ __launch_bounds__(64 * kWavesB, 3) void aev_backward_fast(AevParams p, AevArgs a, int cap, int rowf, RepTab rep) {
+template <int NA, int NZ, int NCH, int GR, bool VIR>
+__global__ __launch_bounds__(64 * kWavesB, ANI_BWD_MINW) void aev_backward_fast(AevParams p, AevArgs a, int cap, int rowf, RepTab rep) {
   extern __shared__ float4 smem4[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, true, rowf), cap, true, rowf);
-  // dE/dAEV row of the current centre: GR x 16 B per lane (GR = 1 covers rows of up to 256 columns, GR = 4 up to
-  // 1024), issued BEFORE this iteration's prefetch loads so that the wait for it (vmcnt counts in order) leaves the
-  // younger prefetches in flight
-  float4 grow[GR];
   float wv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this lane's share of the wave's virial
   float er = 0.f;                                                // ... and of its repulsion energy
-  const int n4 = p.aev_stride >> 2;
-  ANI_PERSISTENT_LOOP(kWavesB, NCH,
-                      {
-                        const float4* g4 = reinterpret_cast<const float4*>(a.gaev + (long long)row * p.aev_stride);
-                        _Pragma("unroll") for (int c = 0; c < GR; c++) grow[c] =
-                            (cur.info.x >= 0 && lane + 64 * c < n4) ? g4[lane + 64 * c] : make_float4(0, 0, 0, 0);
-                      },
-                      (backward_centre<NA, NZ, NCH, GR>(p, a, cap, L, row, cur, grow, lane, wv, rep, er)))
+  ANI_PERSISTENT_LOOP(kWavesB, NCH, true, GR,
+                      (backward_centre<NA, NZ, NCH, GR, VIR>(p, a, L, row, hc, cur, lane, wv, rep, er, secure)))
   if (rep.on) {
     double se = (double)er;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
     if (lane == 0) atomicAdd(&rep.erep[(blockIdx.x * kWavesB + wave) & (kVirialSlots - 1)], se);
   }
-  if (a.virial) {
+  if constexpr (VIR) {
+    if (a.virial) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-      double sv = (double)wv[k];
+      for (int k = 0; k < 9; k++) {
+        double sv = (double)wv[k];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off);
-      if (lane == 0) atomicAdd(&a.virial[9 * ((blockIdx.x * kWavesB + wave) & (kVirialSlots - 1)) + k], -sv);
+        for (int off = 32; off > 0; off >>= 1) sv += __shfl_xor(sv, off);
+        if (lane == 0) atomicAdd(&a.virial[9 * ((blockIdx.x * kWavesB + wave) & (kVirialSlots - 1)) + k], -sv);
+      }
     }
   }
 }
@@ -1127,6 +1352,21 @@ static void launch_fast(K kernel, const AevParams& p, const AevArgs& a, int wave
                      extra...);
 }
 
+int aev_compact_stride(const AevParams& p, int max_numneigh) {
+  return aev_fast_path(p, max_numneigh) ? kMaxAng + radial_cap(p, max_numneigh) : 0;
+}
+
+void launch_nbr_compact(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
+  if (a.nrows <= 0 || !aev_fast_path(p, max_numneigh)) return;
+  const int cap = radial_cap(p, max_numneigh);
+  auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.nrows, kWavesC, 0)), dim3(64 * kWavesC), 0, st, p, a, cap);
+  };
+  if (max_numneigh <= 128) go(nbr_compact_kernel<2>);
+  else if (max_numneigh <= 192) go(nbr_compact_kernel<3>);
+  else go(nbr_compact_kernel<4>);
+}
+
 void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
   if (a.nrows <= 0) return;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
@@ -1134,11 +1374,13 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
     const int cap = radial_cap(p, max_numneigh);
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, false, rowf) * 4 * kWaves;
-    const bool k1 = fast_kind(p) == 1, n3 = max_numneigh <= 192;
-    if (k1 && n3) launch_fast(aev_forward_fast<8, 4, 3>, p, a, kWaves, lds, cap, rowf, st);
-    else if (k1) launch_fast(aev_forward_fast<8, 4, 4>, p, a, kWaves, lds, cap, rowf, st);
-    else if (n3) launch_fast(aev_forward_fast<4, 8, 3>, p, a, kWaves, lds, cap, rowf, st);
-    else launch_fast(aev_forward_fast<4, 8, 4>, p, a, kWaves, lds, cap, rowf, st);
+    // 64-entry chunks of the radial-only stream prefetched per centre: 1 with the radial screen on (more than 64
+    // neighbours between Rca and Rcr are loaded in place), 3 in pyaev mode where every candidate stays
+    const bool k1 = fast_kind(p) == 1, n2 = !p.compat;
+    if (k1 && n2) launch_fast(aev_forward_fast<8, 4, 1>, p, a, kWaves, lds, cap, rowf, st);
+    else if (k1) launch_fast(aev_forward_fast<8, 4, 3>, p, a, kWaves, lds, cap, rowf, st);
+    else if (n2) launch_fast(aev_forward_fast<4, 8, 1>, p, a, kWaves, lds, cap, rowf, st);
+    else launch_fast(aev_forward_fast<4, 8, 3>, p, a, kWaves, lds, cap, rowf, st);
   } else {
     hipLaunchKernelGGL(aev_forward_generic, grid, block, 0, st, p, a);
   }
@@ -1153,18 +1395,22 @@ bool launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
     const int cap = radial_cap(p, max_numneigh);
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, true, rowf) * 4 * kWavesB;
-    const bool k1 = fast_kind(p) == 1, n3 = max_numneigh <= 192, g1 = p.aev_stride <= 256;
-#define ANI_BWD_CASE(NA, NZ, NCH, GR) launch_fast(aev_backward_fast<NA, NZ, NCH, GR>, p, a, kWavesB, lds, cap, rowf, st, rt)
+    const bool k1 = fast_kind(p) == 1, n2 = !p.compat, g1 = p.aev_stride <= 256;
+#define ANI_BWD_CASE(NA, NZ, NCH, GR)                                                                   \
+  do {                                                                                                  \
+    if (a.virial) launch_fast(aev_backward_fast<NA, NZ, NCH, GR, true>, p, a, kWavesB, lds, cap, rowf, st, rt);  \
+    else launch_fast(aev_backward_fast<NA, NZ, NCH, GR, false>, p, a, kWavesB, lds, cap, rowf, st, rt);          \
+  } while (0)
     if (k1) {
-      if (n3 && g1) ANI_BWD_CASE(8, 4, 3, 1);
-      else if (n3) ANI_BWD_CASE(8, 4, 3, 4);
-      else if (g1) ANI_BWD_CASE(8, 4, 4, 1);
-      else ANI_BWD_CASE(8, 4, 4, 4);
+      if (n2 && g1) ANI_BWD_CASE(8, 4, 1, 1);
+      else if (n2) ANI_BWD_CASE(8, 4, 1, 4);
+      else if (g1) ANI_BWD_CASE(8, 4, 3, 1);
+      else ANI_BWD_CASE(8, 4, 3, 4);
     } else {
-      if (n3 && g1) ANI_BWD_CASE(4, 8, 3, 1);
-      else if (n3) ANI_BWD_CASE(4, 8, 3, 4);
-      else if (g1) ANI_BWD_CASE(4, 8, 4, 1);
-      else ANI_BWD_CASE(4, 8, 4, 4);
+      if (n2 && g1) ANI_BWD_CASE(4, 8, 1, 1);
+      else if (n2) ANI_BWD_CASE(4, 8, 1, 4);
+      else if (g1) ANI_BWD_CASE(4, 8, 3, 1);
+      else ANI_BWD_CASE(4, 8, 3, 4);
     }
 #undef ANI_BWD_CASE
     return true;
