@@ -178,11 +178,12 @@ int ani_set_option(ani_handle* h, const char* name, int value);
 /* copy `bytes` from a device pointer of the view to host memory (synchronises the handle's stream first) */
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes);
 
-/* kernel timing hooks for bench.py: brackets the AEV / MLP phases of the NEXT computes with hipEvents on the
- * compute stream; ani_phase_times returns accumulated milliseconds {aev_fwd, mlp, aev_bwd, other} and call count.
- * enable: 1 = start a fresh accumulation, 0 = stop recording (what was recorded stays readable), 2 = resume. */
+/* kernel timing hooks for bench.py: brackets the phases of the NEXT computes with hipEvents on the compute stream;
+ * ani_phase_times returns accumulated milliseconds {aev_fwd, mlp, aev_bwd, other (finish), pack + neighbour compaction}
+ * and the call count.  enable: 1 = start a fresh accumulation, 0 = stop recording (what was recorded stays readable),
+ * 2 = resume. */
 int ani_phase_timing(ani_handle* h, int enable);
-int ani_phase_times(ani_handle* h, double* ms4, int* ncalls);
+int ani_phase_times(ani_handle* h, double* ms5, int* ncalls);
 
 #ifdef __cplusplus
 }

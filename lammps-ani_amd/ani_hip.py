@@ -203,7 +203,7 @@ class ANI:
         self._check(self._lib.ani_phase_timing(self._h, int(enable)))
 
     def phase_times(self):
-        ms = (C.c_double * 4)()
+        ms = (C.c_double * 5)()
         n = C.c_int()
         self._check(self._lib.ani_phase_times(self._h, ms, C.byref(n)))
-        return dict(aev_fwd=ms[0], mlp=ms[1], aev_bwd=ms[2], other=ms[3], calls=n.value)
+        return dict(aev_fwd=ms[0], mlp=ms[1], aev_bwd=ms[2], other=ms[3], compact=ms[4], calls=n.value)

@@ -115,3 +115,163 @@ def _factor3(n):
             if max(a, b, c) < max(best):
                 best = tuple(sorted((a, b, c), reverse=True))
     return best
+
+
+class DomainComm:
+    """LAMMPS ``Comm`` for a brick decomposition, with every array on the device: what ``Comm::exchange`` (owned atoms
+    that left the sub-box migrate to their new owner), ``Comm::borders`` (ghost atoms within ``cutghost`` of the sub-box,
+    periodic images included), ``Comm::forward_comm`` (ghost positions) and the pair style's ``comm->reverse_comm(this)``
+    (ghost forces summed into their owners, src/pair_ani.cpp:197-201,461-484) do on the host in the reference's runs.
+
+    The ghost set is the one LAMMPS' six face swaps produce — every atom image inside the sub-box widened by
+    ``cutghost`` — but built in ONE step: each rank tests its owned atoms against the (destination brick, image shift)
+    combinations that can reach them, and each peer receives one message per direction (`all_to_all_single` with per-peer
+    splits: RCCL on the GPU box, gloo in the CPU tests).  Ghosts arrive grouped by sending rank, so the forward exchange
+    writes the ghost block in place and the reverse exchange is one `index_add_` on the sender's list.
+
+    Layout after ``borders``: ``x[:nlocal]`` owned atoms, ``x[nlocal:]`` ghosts in arrival order.
+    """
+
+    def __init__(self, grid, box_lo, box_len, cutghost, device, group=None, periodic=(True, True, True)):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        px, py, pz = grid
+        assert px * py * pz == self.world, (grid, self.world)
+        self.grid = (px, py, pz)
+        self.device = device
+        self.cut = float(cutghost)
+        self.periodic = tuple(bool(v) for v in periodic)
+        self.lo_np = np.asarray(box_lo, dtype=np.float64)
+        self.len_np = np.asarray(box_len, dtype=np.float64)
+        self.box_lo = torch.as_tensor(self.lo_np, device=device)
+        self.box_len = torch.as_tensor(self.len_np, device=device)
+        self.host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda")
+        r = self.rank
+        self.me = (r % px, (r // px) % py, r // (px * py))   # harness/lmp_harness.cpp: rank = ix + px*(iy + py*iz)
+        P = np.array(self.grid, dtype=np.float64)
+        self.sub_lo = self.lo_np + self.len_np * np.array(self.me) / P
+        self.sub_hi = self.lo_np + self.len_np * (np.array(self.me) + 1) / P
+        # per dimension: the (brick, image shift) combinations whose widened brick can contain an image of an atom owned
+        # here; [lo, hi) is the interval of the UNSHIFTED coordinate that qualifies
+        combos = []
+        for d in range(3):
+            nimg = int(np.ceil(self.cut / self.len_np[d])) if self.periodic[d] else 0
+            cd = []
+            for b in range(self.grid[d]):
+                blo = self.lo_np[d] + self.len_np[d] * b / self.grid[d]
+                bhi = self.lo_np[d] + self.len_np[d] * (b + 1) / self.grid[d]
+                for s in range(-nimg, nimg + 1):
+                    lo, hi = blo - self.cut - s * self.len_np[d], bhi + self.cut - s * self.len_np[d]
+                    if hi > self.sub_lo[d] and lo < self.sub_hi[d]:
+                        cd.append((b, s, lo, hi))
+            combos.append(cd)
+        full = []
+        for ix, (bx, sx, _, _) in enumerate(combos[0]):
+            for iy, (by, sy, _, _) in enumerate(combos[1]):
+                for iz, (bz, sz, _, _) in enumerate(combos[2]):
+                    if (bx, by, bz) == self.me and (sx, sy, sz) == (0, 0, 0):
+                        continue   # the owned atoms themselves
+                    full.append((bx + px * (by + py * bz), ix, iy, iz, sx, sy, sz))
+        full.sort(key=lambda t: t[0])   # by destination rank: the hits then come out grouped by peer
+        self._dest = torch.tensor([t[0] for t in full], dtype=torch.long, device=device)
+        self._cidx = [torch.tensor([t[1 + d] for t in full], dtype=torch.long, device=device) for d in range(3)]
+        self._shift = torch.tensor([[t[4], t[5], t[6]] for t in full], dtype=torch.float64, device=device) * self.box_len
+        self._lo = [torch.tensor([c[2] for c in combos[d]], dtype=torch.float64, device=device)[:, None] for d in range(3)]
+        self._hi = [torch.tensor([c[3] for c in combos[d]], dtype=torch.float64, device=device)[:, None] for d in range(3)]
+        self.nlocal = 0
+        self.nghost = 0
+        self.send_idx = torch.zeros(0, dtype=torch.long, device=device)
+        self.send_shift = torch.zeros((0, 3), dtype=torch.float64, device=device)
+        self.send_splits = [0] * self.world
+        self.recv_splits = [0] * self.world
+
+    # ---- plumbing -----------------------------------------------------------------------------------------------
+    def _counts(self, send_counts):
+        """exchange per-peer message sizes (one host round trip; rebuild steps only)"""
+        if self.world == 1:
+            return list(send_counts)
+        sc = torch.as_tensor(send_counts, dtype=torch.int64, device="cpu" if self.host_staged or dist.get_backend(self.group) == "gloo" else self.device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        return rc.cpu().tolist()
+
+    def _a2a(self, inp, out_splits, in_splits):
+        out = torch.empty((int(sum(out_splits)),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+        if self.world == 1:
+            out.copy_(inp)
+        elif self.host_staged:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu().contiguous(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group)
+        return out
+
+    # ---- Comm::exchange -------------------------------------------------------------------------------------------
+    def exchange(self, x, *per_atom):
+        """x: [nlocal,3] owned positions (any image); per_atom: further [nlocal,...] tensors that travel with their atom.
+        Wraps positions into the box (Domain::pbc) and hands every atom to the rank whose brick now holds it.
+        Returns the new (x, *per_atom) of this rank; atoms that stay keep their relative order."""
+        L, lo = self.box_len, self.box_lo
+        x = x.clone()
+        for d in range(3):
+            if self.periodic[d]:
+                x[:, d] -= torch.floor((x[:, d] - lo[d]) / L[d]) * L[d]
+                x[:, d] = torch.where(x[:, d] >= lo[d] + L[d], lo[d], x[:, d])
+        if self.world == 1:
+            return (x,) + tuple(per_atom)
+        P = torch.tensor(self.grid, dtype=torch.float64, device=x.device)
+        b = torch.floor((x - lo) / L * P).long()
+        b = torch.minimum(torch.clamp(b, min=0), torch.tensor(self.grid, device=x.device) - 1)
+        dest = b[:, 0] + self.grid[0] * (b[:, 1] + self.grid[1] * b[:, 2])
+        order = torch.argsort(dest, stable=True)
+        send = torch.bincount(dest, minlength=self.world).cpu().tolist()
+        recv = self._counts(send)
+        out = []
+        for t in (x,) + tuple(per_atom):
+            out.append(self._a2a(t[order], recv, send))
+        return tuple(out)
+
+    # ---- Comm::borders --------------------------------------------------------------------------------------------
+    def borders(self, x, species):
+        """x: [nlocal,3] owned positions inside this rank's brick, species: [nlocal].  Selects what every peer (and this
+        rank itself, for periodic self-images) needs as ghosts, exchanges it, and returns (x_all, species_all) with the
+        ghosts appended."""
+        n = x.shape[0]
+        m = []
+        for d in range(3):
+            xd = x[:, d][None, :]
+            m.append((xd >= self._lo[d]) & (xd < self._hi[d]))          # [combos_d, n]
+        mask = m[0][self._cidx[0]] & m[1][self._cidx[1]] & m[2][self._cidx[2]]   # [combos, n]
+        hit = mask.nonzero()                                           # combo-major, atoms ascending
+        self.send_idx = hit[:, 1].contiguous()
+        self.send_shift = self._shift[hit[:, 0]]
+        send = torch.bincount(self._dest[hit[:, 0]], minlength=self.world).cpu().tolist()
+        self.send_splits = send
+        self.recv_splits = self._counts(send)
+        self.nlocal = n
+        self.nghost = int(sum(self.recv_splits))
+        gx = self._a2a(x[self.send_idx] + self.send_shift, self.recv_splits, self.send_splits)
+        gs = self._a2a(species[self.send_idx], self.recv_splits, self.send_splits)
+        return torch.cat([x, gx]).contiguous(), torch.cat([species, gs]).contiguous()
+
+    # ---- per step -------------------------------------------------------------------------------------------------
+    def forward_positions(self, x):
+        """x: [nlocal + nghost, 3]; refreshes the ghost block from the owners' current positions."""
+        if self.nghost == 0 and self.send_idx.numel() == 0:
+            return
+        msg = x[: self.nlocal][self.send_idx] + self.send_shift
+        if self.world == 1:
+            x[self.nlocal:] = msg
+        else:
+            x[self.nlocal:] = self._a2a(msg, self.recv_splits, self.send_splits)
+
+    def reverse_add(self, f):
+        """f: [nlocal + nghost, 3]; adds every ghost's force into its owner's row (on whichever rank that is)."""
+        if self.nghost == 0 and self.send_idx.numel() == 0:
+            return
+        g = f[self.nlocal:]
+        if self.world > 1:
+            g = self._a2a(g, self.send_splits, self.recv_splits)
+        f[: self.nlocal].index_add_(0, self.send_idx, g)

@@ -115,12 +115,12 @@ struct ani_handle {
 
   // phase timing
   bool timing = false;
-  // one set of 5 events per timed step, recorded on the compute stream without synchronising; elapsed times are
+  // one set of 6 events per timed step, recorded on the compute stream without synchronising; elapsed times are
   // resolved lazily in ani_phase_times() so the timed region of a benchmark is not perturbed
   std::vector<hipEvent_t> evt_pool;
   size_t evt_used = 0;
   hipEvent_t* evt = nullptr;
-  double phase_ms[4] = {0, 0, 0, 0};
+  double phase_ms[5] = {0, 0, 0, 0, 0};   // aev_fwd, mlp, aev_bwd, other, nbr_compact
   int phase_calls = 0;
 };
 
@@ -329,6 +329,9 @@ int rebuild(ani_handle* h, hipStream_t st) {
   HIP_TRY(h, h->centre_of_row.reserve(nrows_cap));
   HIP_TRY(h, h->row_info.reserve(nrows_cap));
   HIP_TRY(h, h->bucket_info.reserve(kBucketInfoInts));
+  // a capacity overflow of an earlier epoch must not poison this one (the flag turns the device path's energy into NaN)
+  HIP_TRY(h, h->err_flag.reserve(1, true));
+  HIP_TRY(h, hipMemsetAsync(h->err_flag.p, 0, sizeof(int), st));
   PrepOut o{h->nbr_off.p, h->row_of_centre.p, h->centre_of_row.p, h->row_info.p, h->bucket_info.p};
   launch_prepare(h->species.p, h->ilist.p, h->numneigh.p, nlocal, h->ntotal, m.S, nrows_cap, o, st);
   int info[kBucketInfoInts];
@@ -622,13 +625,13 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   HIP_TRY(h, h->virial_acc.reserve(9 * kVirialSlots));
   HIP_TRY(h, h->err_flag.reserve(1, true));
   if (h->timing) {
-    if (h->evt_used + 5 > h->evt_pool.size()) {
+    if (h->evt_used + 6 > h->evt_pool.size()) {
       const size_t old = h->evt_pool.size();
-      h->evt_pool.resize(old + 5 * 64, nullptr);
+      h->evt_pool.resize(old + 6 * 64, nullptr);
       for (size_t i = old; i < h->evt_pool.size(); i++) HIP_TRY(h, hipEventCreate(&h->evt_pool[i]));
     }
     h->evt = &h->evt_pool[h->evt_used];
-    h->evt_used += 5;
+    h->evt_used += 6;
   }
 
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[0], st));
@@ -646,6 +649,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   a.err_flag = h->err_flag.p;
   a.cl_hdr = h->cl_hdr.p; a.cl_xyz = h->cl_xyz.p; a.cl_j = h->cl_j.p; a.cl_stride = h->cl_stride;
   launch_nbr_compact(h->ap_run, a, h->max_numneigh, st);
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[5], st));
   launch_aev_forward(h->ap_run, a, h->max_numneigh, st);
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[1], st));
   compute_mlp(h, st);
@@ -1065,20 +1069,23 @@ int ani_phase_timing(ani_handle* h, int enable) {
   return ANI_OK;
 }
 
-int ani_phase_times(ani_handle* h, double* ms4, int* ncalls) {
-  if (!h || !ms4 || !ncalls) return ANI_ERR_ARG;
+int ani_phase_times(ani_handle* h, double* ms5, int* ncalls) {
+  if (!h || !ms5 || !ncalls) return ANI_ERR_ARG;
   // resolve the recorded-but-unread steps (the caller has synchronised, or we wait here for the last event)
-  for (size_t b = 0; b + 5 <= h->evt_used; b += 5) {
+  // events of a step: 0 start, 5 after pack + compaction, 1 after AEV forward, 2 after the MLP, 3 after AEV backward, 4 end
+  for (size_t b = 0; b + 6 <= h->evt_used; b += 6) {
     HIP_TRY(h, hipEventSynchronize(h->evt_pool[b + 4]));
     float t;
-    for (int i = 0; i < 4; i++) {
+    HIP_TRY(h, hipEventElapsedTime(&t, h->evt_pool[b + 0], h->evt_pool[b + 5])); h->phase_ms[4] += t;
+    HIP_TRY(h, hipEventElapsedTime(&t, h->evt_pool[b + 5], h->evt_pool[b + 1])); h->phase_ms[0] += t;
+    for (int i = 1; i < 4; i++) {
       HIP_TRY(h, hipEventElapsedTime(&t, h->evt_pool[b + i], h->evt_pool[b + i + 1]));
       h->phase_ms[i] += t;
     }
     h->phase_calls++;
   }
   h->evt_used = 0;
-  for (int i = 0; i < 4; i++) ms4[i] = h->phase_ms[i];
+  for (int i = 0; i < 5; i++) ms5[i] = h->phase_ms[i];
   *ncalls = h->phase_calls;
   return ANI_OK;
 }

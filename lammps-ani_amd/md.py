@@ -11,13 +11,11 @@ everything resident on the GPU:
 
 Only device memory, streams and torch.distributed come from torch; the arithmetic of the hot path is libani_hip's.
 
-Ghosts at re-neighbouring (LAMMPS: pbc + exchange + borders):
-  * one rank, periodic box (``box_lo`` given): owned atoms are wrapped and the periodic-image ghosts within the
-    neighbour cutoff of the box faces are regenerated on the device — the run can go on indefinitely;
-  * several ranks: atoms never migrate and the ghost set chosen at set-up is kept.  The ghost shell is then taken
-    ``ghost_margin`` wider than the neighbour cutoff and the run stops loudly once an owned atom has moved more than
-    ``ghost_margin / 2`` from its set-up position — enough for the hundreds of steps of a benchmark or a conservation
-    test, not for production MD (that is LAMMPS' job, through pair_ani.cpp).
+Re-neighbouring (LAMMPS: Domain::pbc + Comm::exchange + Comm::borders + Neighbor::build) is done on the device as
+well, by ``comm.DomainComm``: owned atoms are wrapped into the box and handed to the rank whose brick now holds them,
+the ghost shell (periodic images included) is rebuilt from the current positions, then the library builds the full
+list (ani_build_list_device).  One rank or several, the run can go on indefinitely; between rebuilds only the ghost
+positions (forward) and ghost forces (reverse) travel, one message per peer and direction.
 """
 from __future__ import annotations
 
@@ -37,45 +35,31 @@ ANI2X_MASSES = (1.008, 12.011, 14.007, 15.999, 32.06, 18.998, 35.45)
 class VerletRun:
     def __init__(self, ani, inp, box_len, device, dt: float = 0.5, cutoff: float = 5.1, skin: float = 2.0,
                  ghost_margin: float = 0.0, every: int = 10, masses=ANI2X_MASSES, group=None, seed: int = 12345,
-                 langevin=None, box_lo=None):
-        """ani: ani_hip.ANI (full list, any precision); inp: harness.RankInput decomposed with
-        ``skin = skin + ghost_margin``; langevin: None or (T_target, damp_fs) as ``fix langevin T T damp seed``."""
-        from .comm import GhostExchange
+                 langevin=None, box_lo=None, grid=None, periodic=(True, True, True)):
+        """ani: ani_hip.ANI (full list, any precision); inp: harness.RankInput of this rank — only its OWNED atoms
+        (positions, types, global tags) are taken, ghosts and lists are rebuilt here; langevin: None or
+        (T_target, damp_fs) as ``fix langevin T T damp seed``; grid: processor grid (default comm.grid_for(world));
+        ghost_margin: ignored (kept for callers of the earlier fixed-ghost-shell version)."""
+        from .comm import DomainComm, grid_for
         self.ani, self.device, self.group = ani, device, group
-        self.nlocal, self.ntotal = inp.nlocal, inp.ntotal
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.dt, self.cutneigh, self.skin, self.every = float(dt), cutoff + skin, skin, int(every)
-        self.ghost_margin = float(ghost_margin)
-        self.ex = GhostExchange(inp, box_len, device, group=group)
-        self.box_len = torch.as_tensor(np.asarray(box_len, dtype=np.float64), device=device)
-        # single-rank periodic mode: ghosts are regenerated at every re-neighbouring
-        self.reghost = box_lo is not None and self.ex.world == 1
-        if self.reghost:
-            self.box_lo = torch.as_tensor(np.asarray(box_lo, dtype=np.float64), device=device)
-            assert float(self.box_len.min()) >= self.cutneigh, "box shorter than the neighbour cutoff: images beyond +-1 needed"
-            self._image_combos = torch.tensor([(a, b, c) for a in range(3) for b in range(3) for c in range(3) if (a, b, c) != (1, 1, 1)],
-                                              dtype=torch.long, device=device)
-            self._box_lo_np = np.asarray(box_lo, dtype=np.float64)
-            self._box_len_np = np.asarray(box_len, dtype=np.float64)
-        self.x = torch.as_tensor(inp.x, dtype=torch.float64, device=device).contiguous()
-        self.species = torch.as_tensor(inp.species.astype(np.int32), device=device)
-        m = torch.as_tensor(np.asarray(masses, dtype=np.float64), device=device)[self.species[: self.nlocal].long()]
-        self.mass = m[:, None]
-        # per-atom factors of the integrator, expanded once so that each update is ONE fused device kernel
-        self._dtf_over_m = ((0.5 * float(dt) * FTM2V) / self.mass).expand(-1, 3).contiguous()
-        self._lang = None
-        if langevin is not None:
-            T, damp = langevin
-            g1 = (-self.mass / damp / FTM2V).expand(-1, 3).contiguous()
-            g2 = (torch.sqrt(self.mass) * (24.0 * BOLTZ * T / damp / float(dt) / MVV2E) ** 0.5 / FTM2V).expand(-1, 3).contiguous()
-            self._lang = (g1, g2, torch.empty((self.nlocal, 3), dtype=torch.float64, device=device))
-        self.v = torch.zeros((self.nlocal, 3), dtype=torch.float64, device=device)
-        self.f = torch.zeros((self.ntotal, 3), dtype=torch.float64, device=device)
+        box_lo = np.zeros(3) if box_lo is None else np.asarray(box_lo, dtype=np.float64)
+        self._box_lo_np = box_lo
+        self._box_len_np = np.asarray(box_len, dtype=np.float64)
+        self.dc = DomainComm(grid or grid_for(world), box_lo, box_len, self.cutneigh, device, group=group, periodic=periodic)
+        self.ex = self.dc   # the exchange object (forward_positions / reverse_add)
+        self.masses = torch.as_tensor(np.asarray(masses, dtype=np.float64), device=device)
+        self.langevin = langevin
+        n = inp.nlocal
+        self.nlocal = n
+        self.x = torch.as_tensor(inp.x[:n], dtype=torch.float64, device=device).contiguous()
+        self.species = torch.as_tensor(inp.species[:n].astype(np.int32), device=device)
+        self.tag = torch.as_tensor(np.asarray(inp.tag[:n]).astype(np.int64), device=device)
+        self.v = torch.zeros((n, 3), dtype=torch.float64, device=device)
         self.ev = torch.zeros(10, dtype=torch.float64, device=device)
-        self.x_setup = self.x[: self.nlocal].clone()
-        self.x_built = self.x[: self.nlocal].clone()
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed + 7919 * (dist.get_rank(group) if dist.is_initialized() else 0))
-        self.langevin = langevin
         self.step_no = 0
         self.since_build = 0
         self.nbuilds = 0
@@ -94,46 +78,36 @@ class VerletRun:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t)
 
-    def _regenerate_ghosts(self):
-        """Domain::pbc() + Comm::borders() for one rank owning the whole periodic box."""
-        n, L, lo, cut = self.nlocal, self.box_len, self.box_lo, self.cutneigh
-        xl = self.x[:n]
-        xl -= torch.floor((xl - lo) / L) * L
-        near_lo, near_hi = xl < lo + cut, xl >= lo + L - cut
-        # the 26 image shifts at once: cond[s + 1, atom, d] says whether the atom has an image displaced by s box lengths
-        # along d; one nonzero() (one host sync) lists the (shift, atom) pairs shift-major, atoms ascending
-        cond = torch.stack([near_hi, torch.ones_like(near_lo), near_lo], 0)
-        cb = self._image_combos
-        mask = cond[cb[:, 0], :, 0] & cond[cb[:, 1], :, 1] & cond[cb[:, 2], :, 2]
-        hit = mask.nonzero()
-        owner = hit[:, 1]
-        shift = (cb[hit[:, 0]] - 1).to(torch.float64) * L
-        self.ex.reset_single(owner, shift)
-        self.ntotal = n + int(owner.numel())
-        self.x = torch.cat([xl, xl[owner] + shift]).contiguous()
-        self.species = torch.cat([self.species[:n], self.species[:n][owner]]).contiguous()
-        self.f = torch.zeros((self.ntotal, 3), dtype=torch.float64, device=self.device)
+    def _per_atom_factors(self):
+        """mass-dependent factors of the integrator, expanded once per re-neighbouring (atoms may have migrated) so
+        that each update is ONE fused device kernel"""
+        n = self.nlocal
+        m = self.masses[self.species[:n].long()]
+        self.mass = m[:, None]
+        self._dtf_over_m = ((0.5 * self.dt * FTM2V) / self.mass).expand(-1, 3).contiguous()
+        self._lang = None
+        if self.langevin is not None:
+            T, damp = self.langevin
+            g1 = (-self.mass / damp / FTM2V).expand(-1, 3).contiguous()
+            g2 = (torch.sqrt(self.mass) * (24.0 * BOLTZ * T / damp / self.dt / MVV2E) ** 0.5 / FTM2V).expand(-1, 3).contiguous()
+            self._lang = (g1, g2, torch.empty((n, 3), dtype=torch.float64, device=self.device))
 
     def _build_list(self):
-        """Neighbor::build's role: ghosts refreshed, then the full list on the device."""
-        if self.reghost:
-            self._regenerate_ghosts()
-        self.ex.forward_positions(self.x)
-        moved = (self.x[: self.nlocal] - self.x_setup).square().sum(1).max() if self.nlocal else torch.zeros((), device=self.device)
-        moved = self._allreduce_max(moved.reshape(1).clone()) ** 0.5
-        if self.nbuilds and not self.reghost and moved > 0.5 * self.ghost_margin:
-            raise RuntimeError(f"an atom moved {moved:.2f} A from its set-up position, more than ghost_margin/2 = "
-                               f"{0.5 * self.ghost_margin:.2f} A: the fixed ghost shell of this stand-in no longer "
-                               "covers the neighbour cutoff (re-decompose, or raise ghost_margin)")
-        if self.reghost:   # owned atoms were just wrapped into the box and the ghosts lie within cutneigh of its faces
-            lo = self._box_lo_np - self.cutneigh - 0.25
-            hi = self._box_lo_np + self._box_len_np + self.cutneigh + 0.25
-        else:
-            lo = (self.x.min(0).values - 0.25).cpu().numpy()
-            hi = (self.x.max(0).values + 0.25).cpu().numpy()
-        self.npairs = self.ani.build_list_device(self.ntotal, self.nlocal, self.species.data_ptr(), self.x.data_ptr(),
+        """Domain::pbc + Comm::exchange + Comm::borders + Neighbor::build."""
+        n = self.nlocal
+        xo, v, tag, sp = self.dc.exchange(self.x[:n], self.v, self.tag, self.species[:n])
+        self.nlocal = n = xo.shape[0]
+        self.v, self.tag = v.contiguous(), tag.contiguous()
+        self.x, self.species = self.dc.borders(xo, sp.contiguous())
+        self.ntotal = self.x.shape[0]
+        self._per_atom_factors()
+        self.f = torch.zeros((self.ntotal, 3), dtype=torch.float64, device=self.device)
+        # every atom lies inside the rank's brick widened by the ghost cutoff
+        lo = self.dc.sub_lo - self.cutneigh - 0.25
+        hi = self.dc.sub_hi + self.cutneigh + 0.25
+        self.npairs = self.ani.build_list_device(self.ntotal, n, self.species.data_ptr(), self.x.data_ptr(),
                                                  self.cutneigh, lo, hi, stream=self._stream)
-        self.x_built.copy_(self.x[: self.nlocal])
+        self.x_built = self.x[:n].clone()
         self.since_build = 0
         self.nbuilds += 1
 
@@ -141,7 +115,7 @@ class VerletRun:
         self.f.zero_()
         self.ani.compute_device(self.ntotal, self.nlocal, None, self.x.data_ptr(), self.npairs, None, None, None, 1,
                                 self.f.data_ptr(), self.ev.data_ptr(), stream=self._stream)
-        self.ex.reverse_add(self.f)
+        self.dc.reverse_add(self.f)
         if self._lang is not None:
             # fix langevin (LAMMPS fix_langevin.cpp, uniform random numbers in [-0.5, 0.5)): f += g1 v + g2 r on owned atoms
             g1, g2, r = self._lang
@@ -191,11 +165,18 @@ class VerletRun:
         if self.since_build % self.every == 0:
             d2 = (self.x[: self.nlocal] - self.x_built).square().sum(1).max().reshape(1) if self.nlocal else \
                 torch.zeros(1, dtype=torch.float64, device=self.device)
-            rebuild = self._allreduce_max(d2.clone()) > (0.5 * self.skin) ** 2
+            # the same host round trip carries the health of the last force evaluation: the device entry point cannot
+            # return ANI_ERR_CAPACITY (nothing synchronises), it turns the energy into NaN instead
+            d2 = torch.where(torch.isfinite(self.ev[:1]), d2, torch.full_like(d2, float("inf")))
+            worst = self._allreduce_max(d2.clone())
+            if worst == float("inf"):
+                raise RuntimeError("non-finite energy from the device step: a neighbour count exceeded the kernels' LDS "
+                                   "capacity (ANI_ERR_CAPACITY) or the forces diverged")
+            rebuild = worst > (0.5 * self.skin) ** 2
         if rebuild:
             self._build_list()
         else:
-            self.ex.forward_positions(self.x)
+            self.dc.forward_positions(self.x)
         self._forces()
         # fix nve final_integrate
         self.v.addcmul_(self.f[: self.nlocal], self._dtf_over_m)

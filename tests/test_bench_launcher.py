@@ -1,0 +1,53 @@
+"""CPU: `bench.py --gpus N` launches its own ranks.  With N > 1 and no WORLD_SIZE the parent must start
+`python -m torch.distributed.run --nproc-per-node N ... bench.py` as a CHILD before anything touches a GPU (the driver
+runs `python3 bench.py --gpus 8`; the reference does `mpirun -np {num_gpus}`, examples/benchmark/run_one.py:48), relay
+the JSON line and pass the exit code on.  In this container there is no GPU, so the ranks must get as far as the
+device check and fail THERE — each rank with the no-device message — and the parent must report failure."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_parent_launches_two_ranks_that_reach_the_device_check():
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: the launcher is exercised for real by the multi-rank GPU tests")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"ANI_BENCH_BACKEND": "gloo"})
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""                       # no JSON line from a failed run
+    assert r.stderr.count("no HIP device visible") == 2   # both ranks were started and got to the device check
+    assert "SystemExit: --gpus" not in r.stderr and "must be launched with" not in r.stderr
+
+
+def test_relay_prints_only_the_json_line_and_passes_the_exit_code(tmp_path):
+    """The relay logic alone, with a stand-in for torch.distributed.run: a fake `torch.distributed.run` module earlier on
+    PYTHONPATH that prints noise plus a JSON line and exits with a chosen code."""
+    pkg = tmp_path / "torch" / "distributed"
+    pkg.mkdir(parents=True)
+    (tmp_path / "torch" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("")
+    (pkg / "run.py").write_text(
+        "import sys, json\n"
+        "print('banner noise')\n"
+        "print(json.dumps({'metric': 'x', 'argv': sys.argv[1:]}))\n"
+        "sys.exit(int(__import__('os').environ.get('FAKE_RC', '0')))\n")
+    for rc in (0, 3):
+        r = _run(["--gpus", "4", "--steps", "7"], {"PYTHONPATH": str(tmp_path), "FAKE_RC": str(rc)})
+        assert r.returncode == rc
+        lines = r.stdout.splitlines()
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        argv = d["argv"]
+        assert "--nproc-per-node=4" in argv and "--nnodes=1" in argv
+        assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+        assert argv[-4:] == ["--gpus", "4", "--steps", "7"] and argv[-5].endswith("bench.py")

@@ -18,7 +18,7 @@ sysm = harness.spatial_sort(harness.water_box(natoms))
 inp = harness.decompose(sysm, skin=2.0 + margin)
 ani = ani_hip.ANI(path, 0, use_single=bool(single))
 dev = torch.device("cuda:0")
-run = md.VerletRun(ani, inp, sysm.boxhi - sysm.boxlo, dev, dt=dt, ghost_margin=margin, box_lo=sysm.boxlo, langevin=lang)
+run = md.VerletRun(ani, inp, sysm.boxhi - sysm.boxlo, dev, dt=dt, box_lo=sysm.boxlo, langevin=lang)
 # list check against the harness at set-up
 inp7 = harness.decompose(sysm, skin=2.0 + margin)  # ghosts identical; host list has the wider cutoff, so rebuild at 7.1
 nn, jl = ani.debug_list(inp.nlocal)
@@ -31,6 +31,6 @@ for s in range(1, steps + 1):
     run.step()
     if s % max(1, steps // 10) == 0:
         pe, ke = run.potential_energy(), run.kinetic_energy()
-        moved = float((run.x[:run.nlocal] - run.x_setup).square().sum(1).max()) ** 0.5
+        moved = float((run.x[:run.nlocal] - run.x_built).square().sum(1).max()) ** 0.5
         print(f"step {s} pe {pe:.4f} ke {ke:.4f} etot {pe+ke:.4f} drift {pe+ke-e0:+.5f} T {2*ke/(3*run.nlocal-3)/md.BOLTZ:.1f} builds {run.nbuilds} moved {moved:.2f}")
 torch.cuda.synchronize(); print("ms/step", (time.time() - t0) / steps * 1e3)
