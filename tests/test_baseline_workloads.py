@@ -1,0 +1,103 @@
+"""GPU parity on the BASELINE.json workloads themselves, at their own sizes, against the fp64 oracle
+(oracle/ani_oracle.c, OpenMP — seconds at these sizes):
+
+  * configs[1]: the ~10k-atom water box with the full 8-member ANI-2x-shaped ensemble, fp32 — energy, every force
+    component, virial;
+  * configs[4] (one GPU's worth of it): a CH4:O2 combustion box, ANI-1x-shaped 8-member ensemble with the pairwise
+    repulsion of the reactive models, through BOTH precisions of the library (the fp32 MFMA path at the fp32 bars, the
+    fp64 kernels at 1e-8), plus the "fp32 vs fp64 force tolerance sweep" the config names: the fp32 path against the
+    fp64 kernels over gas densities from the reference's 0.25 g/cm3 up to 4x that.
+
+configs[2] (100 002 atoms) is covered by test_hip_properties.py::test_full_size_water_box_properties and, against the
+oracle, by every bench.py run (`parity` block); configs[3] and the 8-GPU part of configs[4] need an 8-GPU node.
+Synthetic seeded weights (no trained weights in the container): parity here is HIP path == restatement.
+"""
+import numpy as np
+import pytest
+
+from lammps_ani_amd import harness as hx
+
+pytestmark = pytest.mark.gpu
+
+F_TOL = 2.3e-3            # kcal/mol/A = 1e-4 eV/A (north-star bar)
+E_TOL_PER_ATOM = 1e-5     # kcal/mol per atom: fp32 per-atom network outputs summed in fp64
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from lammps_ani_amd import ani_hip
+    return ani_hip
+
+
+def _check(got, ref, natoms, f_tol, e_tol, v_tol, ea_tol=2e-3):
+    assert np.isfinite(got["energy"])
+    assert abs(got["energy"] - ref["energy"]) < e_tol, (got["energy"], ref["energy"])
+    err = np.abs(got["force"] - ref["force"])
+    assert err.max() < f_tol, err.max()
+    assert np.abs(got["virial"] - ref["virial"]).max() < v_tol
+    assert np.abs(got["eatom"] - ref["eatom"]).max() < ea_tol
+    return err
+
+
+def test_config1_water_10k_8_members_against_oracle(model_cache, hip):
+    from oracle import Oracle
+    p = model_cache("ani2x", 8, 2024)
+    inp = hx.decompose(hx.spatial_sort(hx.water_box(10002, seed=12345)))
+    ref = Oracle(p).compute(inp)
+    ani = hip.ANI(p, 0, -1)
+    assert ani.use_num_models == 8
+    got = ani.compute(inp, ago=0)
+    err = _check(got, ref, inp.nlocal, F_TOL, E_TOL_PER_ATOM * inp.nlocal, 1.0)
+    rms = float(np.sqrt((err ** 2).mean()))
+    print(f"water-10002 x 8: max |dF| {err.max():.2e}, rms {rms:.2e} kcal/mol/A, |dE| {abs(got['energy'] - ref['energy']):.2e} kcal/mol")
+    assert rms < 3e-4
+    # the same list through ago > 0 with moved atoms (what every MD step between rebuilds does)
+    moved = hx.RankInput(**{**inp.__dict__, "x": inp.x + np.random.default_rng(1).normal(0, 0.02, size=inp.x.shape)})
+    # ghosts must move with their owners for the comparison to be a consistent configuration
+    moved.x[inp.nlocal:] = inp.x[inp.nlocal:] + (moved.x[inp.owner_lidx] - inp.x[inp.owner_lidx])
+    ref2 = Oracle(p).compute(moved)
+    got2 = ani.compute(moved, ago=1)
+    _check(got2, ref2, inp.nlocal, F_TOL, E_TOL_PER_ATOM * inp.nlocal, 1.0)
+    ani.close()
+
+
+@pytest.mark.parametrize("single", [True, False], ids=["fp32", "fp64"])
+def test_config4_combustion_box_with_repulsion_against_oracle(single, model_cache, hip):
+    from oracle import Oracle
+    p = model_cache("ani1x", 8, 2024, repulsion=True)
+    sysm = hx.spatial_sort(hx.combustion_box(21000, seed=12345))      # CH4 : O2 = 1 : 2, 0.25 g/cm3 as the reference's box
+    inp = hx.decompose(sysm)
+    ref = Oracle(p).compute(inp)
+    ani = hip.ANI(p, 0, -1, use_single=single)
+    got = ani.compute(inp, ago=0)
+    if single:
+        err = _check(got, ref, inp.nlocal, F_TOL, E_TOL_PER_ATOM * inp.nlocal, 1.0)
+    else:
+        # fp64: the reference's own fp64 bars are 1e-8 on forces and 9e-9 RELATIVE on the energy;
+        # |E| is 5e8 kcal/mol here (self energies), so the summation order alone is worth a few 1e-4
+        err = _check(got, ref, inp.nlocal, 1e-8, 5e-12 * abs(ref["energy"]), 1e-9 * np.abs(ref["virial"]).max(), ea_tol=1e-8)
+    print(f"combustion-{inp.nlocal} {'fp32' if single else 'fp64'}: max |dF| {err.max():.2e} kcal/mol/A, "
+          f"{inp.npairs / inp.nlocal:.1f} list entries per atom")
+    ani.close()
+
+
+@pytest.mark.parametrize("density", [0.25, 0.5, 0.8])
+def test_config4_fp32_vs_fp64_force_sweep_on_the_combustion_box(density, model_cache, hip):
+    """BASELINE.json configs[4]: "fp32 vs fp64 force tolerance sweep" — the fp32 path (split-bf16 MFMA MLP, hardware
+    transcendentals) against the library's own fp64 kernels on the reactive mixture, from the reference's gas density
+    to a compressed fluid (more neighbours, larger repulsive forces)."""
+    p = model_cache("ani1x", 8, 2024, repulsion=True)
+    sysm = hx.spatial_sort(hx.combustion_box(24000, seed=7, density=density))
+    inp = hx.decompose(sysm)
+    a32 = hip.ANI(p, 0, -1, use_single=True)
+    a64 = hip.ANI(p, 0, -1, use_single=False)
+    g32, g64 = a32.compute(inp, ago=0), a64.compute(inp, ago=0)
+    err = np.abs(g32["force"] - g64["force"])
+    scale = np.abs(g64["force"]).max()
+    print(f"rho {density}: {inp.npairs / inp.nlocal:.1f} list entries/atom, max |F| {scale:.1f}, max |dF| {err.max():.2e}, "
+          f"rms {np.sqrt((err ** 2).mean()):.2e} kcal/mol/A, |dE| {abs(g32['energy'] - g64['energy']):.2e}")
+    # absolute bar of the north star, widened relatively where the repulsive wall makes forces of hundreds of kcal/mol/A
+    assert err.max() < max(F_TOL, 2e-5 * scale)
+    assert abs(g32["energy"] - g64["energy"]) < E_TOL_PER_ATOM * inp.nlocal
+    a32.close()
+    a64.close()
