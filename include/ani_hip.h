@@ -169,12 +169,26 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *   "mlp_chain" (default 1): with one ensemble member and few row tiles (small systems) the six MLP products run as one
  *       chained launch instead of six grouped ones; 2 = at any size (measurement knob), 0 = never.  Takes effect at the
  *       next call.
+ *   "profiling" (default 0): the reference's LAMMPS_ANI_PROFILING (src/pair_ani.cpp:49-50, src/pair_ani_kokkos.cpp:68-70,
+ *       210-212): ani_compute_full_device synchronises its stream before it returns, so the caller's host timers
+ *       (LAMMPS' timing breakdown) charge the device work to the pair style.  The host-pointer entry points always
+ *       synchronise.  Takes effect at the next call.
  *   "full_radial_capacity" (default 0): with the radial screen at Rcr (use_cuaev = 1) the kernels reserve LDS for 3/4
  *       of the longest neighbour list (>= 128 entries) per centre -- a uniform 7.1 A list holds 37 % of its entries
  *       inside 5.1 A -- instead of all of it; a centre that needs more raises ANI_ERR_CAPACITY.  1 reserves the full
  *       list length (takes effect at the next call).
  */
 int ani_set_option(ani_handle* h, const char* name, int value);
+/*
+ * Profiler timeline markers (rocprofv3 --marker-trace; roctx underneath).  The library brackets its own phases ("ani:
+ * neighbour compaction", "ani: AEV forward", "ani: MLP forward + backward", "ani: AEV backward + finish") and marks
+ * "neighbor list rebuilt" like the reference (NVTX: src/ani_csrc/ani.cpp:128,215); the adapter uses these three to
+ * bracket its own work, e.g. "reverse_comm" (src/pair_ani.cpp:198-200), without a tracing dependency of its own.
+ */
+void ani_trace_push(const char* name);
+void ani_trace_pop(void);
+void ani_trace_mark(const char* name);
+
 /* copy `bytes` from a device pointer of the view to host memory (synchronises the handle's stream first) */
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes);
 

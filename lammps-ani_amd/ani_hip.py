@@ -20,7 +20,8 @@ HARTREE2KCALMOL = 627.5094738898777
 
 EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani_use_num_models", "ani_num_species",
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
-           "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times"]
+           "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times",
+           "ani_trace_push", "ani_trace_pop", "ani_trace_mark"]
 
 
 class AniError(RuntimeError):
@@ -34,12 +35,18 @@ class DebugView(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    """Compile libani_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    """Compile libani_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).  force: rebuild every object
+    (make -B) whatever the timestamps say.  Returns the library path; build.last_commands holds the compiler command
+    lines make ran (empty when everything was up to date)."""
     args = ["make", "-C", _CSRC, "-j8"]
     if force:
         args.append("-B")
-    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    out = subprocess.run(args, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    build.last_commands = [ln for ln in out.splitlines() if ln.lstrip().startswith(("hipcc", "g++", "gcc"))]
     return LIB_PATH
+
+
+build.last_commands = []
 
 
 _lib = None

@@ -12,6 +12,7 @@
 #include "../../include/ani_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <algorithm>
 #include <cmath>
@@ -50,6 +51,15 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// roctx range for the profiler's timeline (the reference marks its phases with NVTX: src/pair_ani.cpp:198-200,
+// src/ani_csrc/ani.cpp:128,215); costs nothing measurable when no tool is attached
+struct TraceRange {
+  explicit TraceRange(const char* name) { roctxRangePushA(name); }
+  ~TraceRange() { roctxRangePop(); }
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
+
 struct SpeciesNet {
   // device weights; layouts described in compute_mlp()
   std::vector<float*> W;    // [L-1]   W[k]: [M][d[k+1]][kpad(k)]        forward, k = 0..L-2
@@ -79,6 +89,7 @@ struct ani_handle {
   bool prune = true;  // ani_set_option("prune_absent_species")
   int mlp_chain = 1;   // ani_set_option("mlp_chain"): 1 = one chained launch for the MLP of small systems, 2 = at any size, 0 = never
   ChainPlan chain_plan;
+  bool profiling = false;  // ani_set_option("profiling"): every entry point synchronises its stream before returning
   bool mlp_split = true;  // ani_set_option("mlp_split_bf16"): six bf16 MFMA products per fp32 product instead of fp32-input MFMA
   std::vector<int> colmap;  // ap_run column -> ap column
   int device = 0;
@@ -321,6 +332,8 @@ int specialize(ani_handle* h, int mask) {
 // d_species/d_ilist/d_numneigh/d_jlist already hold this epoch's list in the handle's own buffers.
 int rebuild(ani_handle* h, hipStream_t st) {
   const HostModel& m = h->model;
+  roctxMarkA("neighbor list rebuilt");   // src/ani_csrc/ani.cpp:128,215
+  TraceRange tr("ani: list epoch set-up (offsets, species buckets, segment sort)");
   h->need_origin = true;
   const int nlocal = h->nlocal;
   const int nrows_cap = round_up(nlocal, kRowTile) + m.S * kRowTile;
@@ -412,7 +425,7 @@ int rebuild(ani_handle* h, hipStream_t st) {
 //   W[k]  : [M][d[k+1]][w[k]]   Bt of forward layer k (K = w[k], zero padded)
 //   WT[k] : [M][d[k]][w[k+1]]   Bt of the backward product through layer k (k >= 1);  WT[0]: [aev_len][M*w[1]]
 //   H_k   : [rows][M*w[k]]      activations after layer k-1 (member a at column a*w[k]); overwritten by G_k = dE/dz_k
-void compute_mlp(ani_handle* h, hipStream_t st) {
+int compute_mlp(ani_handle* h, hipStream_t st) {
   const HostModel& m = h->model;
   const int L = m.L, M = m.M;
   const float alpha = (float)m.alpha, inv_alpha = (float)(1.0 / m.alpha);
@@ -517,11 +530,12 @@ void compute_mlp(ani_handle* h, hipStream_t st) {
   if (chain) {
     std::vector<GemmArgs> flat;
     for (const auto& lp : layer_probs) flat.insert(flat.end(), lp.begin(), lp.end());
-    launch_mlp_chain(flat.data(), layer_epi.data(), (int)layer_probs.size(), np, &h->chain_plan, st);
+    HIP_TRY(h, launch_mlp_chain(flat.data(), layer_epi.data(), (int)layer_probs.size(), np, &h->chain_plan, st));
   } else {
     for (size_t l = 0; l < layer_probs.size(); l++)
       launch_gemm_group(layer_probs[l].data(), (int)layer_probs[l].size(), (Epilogue)layer_epi[l], st, h->mlp_split);
   }
+  return ANI_OK;
 }
 
 
@@ -634,6 +648,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
     h->evt_used += 6;
   }
 
+  TraceRange tr_step("ani: step");
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[0], st));
   HIP_TRY(h, h->origin.reserve(3));
   if (h->need_origin) {
@@ -648,11 +663,21 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   a.virial = vflag ? h->virial_acc.p : nullptr;
   a.err_flag = h->err_flag.p;
   a.cl_hdr = h->cl_hdr.p; a.cl_xyz = h->cl_xyz.p; a.cl_j = h->cl_j.p; a.cl_stride = h->cl_stride;
-  launch_nbr_compact(h->ap_run, a, h->max_numneigh, st);
+  {
+    TraceRange tr("ani: neighbour compaction");
+    launch_nbr_compact(h->ap_run, a, h->max_numneigh, st);
+  }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[5], st));
-  launch_aev_forward(h->ap_run, a, h->max_numneigh, st);
+  {
+    TraceRange tr("ani: AEV forward");
+    launch_aev_forward(h->ap_run, a, h->max_numneigh, st);
+  }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[1], st));
-  compute_mlp(h, st);
+  {
+    TraceRange tr("ani: MLP forward + backward");
+    const int rcm = compute_mlp(h, st);
+    if (rcm) return rcm;
+  }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[2], st));
   if (m.has_rep) {
     HIP_TRY(h, h->erep.reserve(kVirialSlots));
@@ -675,6 +700,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
         rt.k[8 * ca + cb] = (float)m.rep_tables[2 * n2 + src];
       }
   }
+  TraceRange tr_bwd("ani: AEV backward + finish");
   const bool rep_done = launch_aev_backward(h->ap_run, a, h->max_numneigh, st, rt.on ? &rt : nullptr) && rt.on;
   if (m.has_rep && !rep_done) {
     RepArgs ra{};
@@ -839,8 +865,15 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
     if (rc) return rc;
     h->have_list = true;
   }
-  return run_step(h, d_x, eflag_atom, vflag, d_f, /*accumulate=*/1, d_ev, d_eatom, st);
+  rc = run_step(h, d_x, eflag_atom, vflag, d_f, /*accumulate=*/1, d_ev, d_eatom, st);
+  // LAMMPS_ANI_PROFILING (src/pair_ani_kokkos.cpp:68-70,210-212): the host's timers see the device work of this call
+  if (rc == ANI_OK && h->profiling) HIP_TRY(h, hipStreamSynchronize(st));
+  return rc;
 }
+
+void ani_trace_push(const char* name) { if (name) roctxRangePushA(name); }
+void ani_trace_pop(void) { roctxRangePop(); }
+void ani_trace_mark(const char* name) { if (name) roctxMarkA(name); }
 
 }  // extern "C"
 
@@ -1040,6 +1073,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   }
   if (strcmp(name, "mlp_split_bf16") == 0) {
     h->mlp_split = value != 0;
+    return ANI_OK;
+  }
+  if (strcmp(name, "profiling") == 0) {
+    h->profiling = value != 0;
     return ANI_OK;
   }
   if (strcmp(name, "full_radial_capacity") == 0) {

@@ -58,7 +58,8 @@ struct ChainPlan {
   size_t bytes = 0;
   std::vector<unsigned char> host;
 };
-void launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st);
+// returns the HIP status of the descriptor upload (a failed allocation must not let the step run on stale activations)
+hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st);
 void free_chain_plan(ChainPlan& p);
 int mlp_chain_slots();   // workgroups the chain kernel can keep resident (2 per CU)
 

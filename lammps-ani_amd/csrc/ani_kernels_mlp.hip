@@ -643,13 +643,13 @@ void free_chain_plan(ChainPlan& p) {
   p.d_desc = nullptr; p.bytes = 0; p.host.clear();
 }
 
-void launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st) {
+hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st) {
   std::vector<int> tile_start(nprob + 1, 0);
   static const int forced_r = [] { const char* e = getenv("ANI_CHAIN_WAVES"); return e ? atoi(e) : 0; }();   // experiment knob: 4 / 8
   const int R = 64;
   for (int i = 0; i < nprob; i++) tile_start[i + 1] = tile_start[i] + layers[i].rows / R;
   const int total = tile_start[nprob];
-  if (total <= 0) return;
+  if (total <= 0) return hipSuccess;
   const size_t b0 = sizeof(GemmArgs) * (size_t)nlayers * nprob, b1 = sizeof(int) * (size_t)nlayers, b2 = sizeof(int) * (size_t)(nprob + 1);
   std::vector<unsigned char> host(b0 + b1 + b2);
   memcpy(host.data(), layers, b0);
@@ -659,11 +659,15 @@ void launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int n
     if (plan->bytes < host.size()) {
       if (plan->d_desc) (void)hipFree(plan->d_desc);
       plan->d_desc = nullptr;
-      if (hipMalloc(&plan->d_desc, host.size()) != hipSuccess) { plan->bytes = 0; return; }
+      const hipError_t e = hipMalloc(&plan->d_desc, host.size());
+      if (e != hipSuccess) { plan->d_desc = nullptr; plan->bytes = 0; plan->host.clear(); return e; }
       plan->bytes = host.size();
     }
+    // a synchronous copy from the pageable vector (a few KB, once per list epoch): the asynchronous form would read
+    // plan->host whenever the DMA gets to it, possibly after the next epoch has reassigned it
+    const hipError_t e = hipMemcpy(plan->d_desc, host.data(), host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { plan->host.clear(); return e; }
     plan->host = host;
-    (void)hipMemcpyAsync(plan->d_desc, plan->host.data(), host.size(), hipMemcpyHostToDevice, st);
   }
   const unsigned char* d = reinterpret_cast<const unsigned char*>(plan->d_desc);
   // no more tiles than CUs: one eight-wave workgroup per CU; otherwise two four-wave workgroups per CU
@@ -674,6 +678,7 @@ void launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int n
   else
     hipLaunchKernelGGL((mlp_chain_x3<2, 4>), dim3(total), dim3(256), 0, st, reinterpret_cast<const GemmArgs*>(d),
                        reinterpret_cast<const int*>(d + b0), reinterpret_cast<const int*>(d + b0 + b1), nlayers, nprob);
+  return hipGetLastError();
 }
 
 // weights -> blocked bf16 planes

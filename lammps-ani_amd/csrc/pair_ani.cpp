@@ -41,8 +41,12 @@ PairANI::PairANI(LAMMPS* lmp) : Pair(lmp) {
   if (strcmp(update->unit_style, "real") != 0) error->all(FLERR, "Pair ani requires real units");
   comm_reverse = 3;
   comm_reverse_off = 3;
+  // src/pair_ani.cpp:49-50: with LAMMPS_ANI_PROFILING set the device work of a step is finished when compute() returns,
+  // so LAMMPS' timing breakdown charges it to Pair (the host-pointer entry points used here synchronise in any case; the
+  // option also covers the device-resident one)
   const char* prof = getenv("LAMMPS_ANI_PROFILING");
   profiling = prof && *prof && strcmp(prof, "0") != 0;
+  printf("LAMMPS_ANI_PROFILING mode: %d\n", profiling ? 1 : 0);
 }
 
 PairANI::~PairANI() {
@@ -84,6 +88,7 @@ void PairANI::create_model() {
   const int rc = ani_create(model_file.c_str(), node_local_rank(), use_num_models, use_cuaev ? 1 : 0, use_fullnbr ? 1 : 0,
                             use_single ? 1 : 0, &ani);
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(nullptr));
+  if (profiling) ani_set_option(ani, "profiling", 1);
 }
 
 /* pair_style ani cutoff model_file device [num_models] [cuaev|pyaev] [full|half] [single|double] [hostlist|devlist] */
@@ -246,7 +251,11 @@ void PairANI::compute(int eflag, int vflag) {
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(ani));
 
   // ghost forces go home from out_force (f's ghost entries are not cleared between steps when newton is off)
-  if (!force->newton) comm->reverse_comm(this);
+  if (!force->newton) {
+    ani_trace_push("reverse_comm");   // src/pair_ani.cpp:198-200
+    comm->reverse_comm(this);
+    ani_trace_pop();
+  }
 
   for (int i = 0; i < ntotal; i++) {
     f[i][0] += out_force[3 * i + 0];

@@ -51,7 +51,7 @@ class PairANI : public Pair {
   int use_num_models = -1;
   bool use_cuaev = true, use_fullnbr = true, use_single = true;
   bool use_devlist = false;  // not part of the restart record (kept byte-compatible with the reference): restarts come back as hostlist
-  bool profiling = false;  // LAMMPS_ANI_PROFILING: report timing honestly (the C ABI is synchronous already)
+  bool profiling = false;  // LAMMPS_ANI_PROFILING: passed to the library as option "profiling" (stream sync before returning)
 
   // list epoch (rebuilt when neighbor->ago == 0), grown 1.5x like the reference (src/pair_ani.cpp:119-127)
   std::vector<int64_t> species;

@@ -246,3 +246,37 @@ def test_energy_is_extensive_under_periodic_replication(model_cache, hip):
     assert np.abs(fb[:n] - fa).max() < 0.5 * F_TOL
     assert np.abs(fb[n:] - fa).max() < 0.5 * F_TOL
     ani.close()
+
+
+def test_profiling_option_and_trace_markers(model_cache, hip):
+    """LAMMPS_ANI_PROFILING / NVTX of the reference (src/pair_ani.cpp:49-50,198-200; src/ani_csrc/ani.cpp:128,215): option
+    "profiling" makes the device entry point finish its work before returning (results unchanged), the roctx wrappers
+    are callable with and without a profiler attached."""
+    import torch
+    lib = hip.lib()
+    lib.ani_trace_mark.argtypes = [hip.C.c_char_p]
+    lib.ani_trace_push.argtypes = [hip.C.c_char_p]
+    lib.ani_trace_mark(b"test marker")
+    lib.ani_trace_push(b"test range")
+    lib.ani_trace_pop()
+    inp = hx.decompose(hx.water_box(1536, seed=2))
+    ani = hip.ANI(model_cache("ani2x", 1, 2024), 0)
+    dev = torch.device("cuda:0")
+    x = torch.as_tensor(inp.x, dtype=torch.float64, device=dev).contiguous()
+    sp = torch.as_tensor(inp.species.astype(np.int32), device=dev)
+    il, nn, jl = (torch.as_tensor(a, device=dev) for a in (inp.ilist, inp.numneigh, inp.jlist))
+    out = []
+    for prof in (0, 1):
+        ani.set_option("profiling", prof)
+        f = torch.zeros((inp.ntotal, 3), dtype=torch.float64, device=dev)
+        ev = torch.zeros(10, dtype=torch.float64, device=dev)
+        ani.compute_device(inp.ntotal, inp.nlocal, sp.data_ptr(), x.data_ptr(), inp.npairs, il.data_ptr(), jl.data_ptr(),
+                           nn.data_ptr(), 0, f.data_ptr(), ev.data_ptr(), vflag=True)
+        if prof:   # no synchronisation needed on our side: the call has already waited for its stream
+            assert torch.cuda.current_stream().query()
+        torch.cuda.synchronize()
+        out.append((f.cpu().numpy(), ev.cpu().numpy()))
+    assert np.abs(out[0][0] - out[1][0]).max() < F_TOL and abs(out[0][1][0] - out[1][1][0]) < 1e-3
+    with pytest.raises(hip.AniError, match="unknown option"):
+        ani.set_option("no_such_option", 1)
+    ani.close()
