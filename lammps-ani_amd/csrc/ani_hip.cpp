@@ -997,7 +997,21 @@ int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
   HIP_TRY(h, hipMemcpyAsync(h->x64.p, coordinates, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyHostToDevice, st));
   rc = run_step(h, h->x64.p, eflag_atom, vflag, h->f64.p, /*accumulate=*/0, h->ev.p, h->eatom.p, st);
   if (rc) return rc;
-  return finish_host(h, ntotal, nlocal, eflag_atom, vflag, out_energy, out_force, out_atomic_energies, out_virial);
+  rc = finish_host(h, ntotal, nlocal, eflag_atom, vflag, out_energy, out_force, out_atomic_energies, out_virial);
+  if (rc == ANI_ERR_CAPACITY && h->use_cuaev && !h->ap_run.full_cap) {
+    // The screened radial lists are sized for 3/4 of the longest candidate list; a system denser than that inside Rcr
+    // (small skin, compressed fluid) is input the reference handles, so the step is repeated once with the capacity of
+    // the full list and the setting kept for the rest of the run.  An overflow that survives (more than kMaxAng
+    // neighbours inside Rca) is still reported.
+    h->ap.full_cap = h->ap_run.full_cap = 1;
+    fprintf(stderr, "libani_hip: radial neighbour capacity exceeded, continuing with full_radial_capacity = 1\n");
+    rc = rebuild(h, st);
+    if (rc) return rc;
+    rc = run_step(h, h->x64.p, eflag_atom, vflag, h->f64.p, /*accumulate=*/0, h->ev.p, h->eatom.p, st);
+    if (rc) return rc;
+    rc = finish_host(h, ntotal, nlocal, eflag_atom, vflag, out_energy, out_force, out_atomic_energies, out_virial);
+  }
+  return rc;
 }
 
 int ani_compute_half(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates, int64_t npairs_half,

@@ -280,3 +280,28 @@ def test_profiling_option_and_trace_markers(model_cache, hip):
     with pytest.raises(hip.AniError, match="unknown option"):
         ani.set_option("no_such_option", 1)
     ani.close()
+
+
+def test_radial_capacity_overflow_is_retried_with_full_capacity(model_cache, hip, capfd):
+    """A geometry whose list sits entirely inside Rcr (atoms on a 2.5 A sphere: every pair closer than 5.1 A, about half
+    of them inside Rca) overflows the screened radial capacity (3/4 of the list, at least 128) but not the angular one:
+    the host entry point repeats the step with the full capacity instead of aborting the run, and says so once."""
+    from oracle import Oracle
+    p = model_cache("ani2x", 1, 2024)
+    n = 140
+    k = np.arange(n) + 0.5
+    phi = np.arccos(1 - 2 * k / n)
+    th = np.pi * (1 + 5 ** 0.5) * k
+    pts = 2.5 * np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], 1)
+    s = hx.System(pts, np.full(n, 1, np.int32), np.full(3, -30.0), np.full(3, 30.0), (False,) * 3)
+    inp = hx.decompose(s)
+    assert inp.numneigh.min() == n - 1
+    ani = hip.ANI(p, 0)
+    got = ani.compute(inp, ago=0)
+    assert "full_radial_capacity = 1" in capfd.readouterr().err
+    ref = Oracle(p).compute(inp)
+    assert np.abs(got["force"] - ref["force"]).max() < 5e-2 and abs(got["energy"] - ref["energy"]) < 5e-2   # forces of 1e3, E 2e4 kcal/mol here
+    got2 = ani.compute(inp, ago=1)           # the setting stays: no second retry, same answer
+    assert "full_radial_capacity" not in capfd.readouterr().err
+    assert np.abs(got2["force"] - got["force"]).max() < 1e-3
+    ani.close()
