@@ -250,6 +250,15 @@ int upload_model(ani_handle* h) {
   for (int k = 0; k < m.nR; k++) p.ShfR[k] = (float)m.ShfR[k];
   for (int k = 0; k < m.nA; k++) p.ShfA[k] = (float)m.ShfA[k];
   for (int k = 0; k < m.nZ; k++) { p.cosZ[k] = (float)cos(m.ShfZ[k]); p.sinZ[k] = (float)sin(m.ShfZ[k]); }
+  {
+    const double dR = m.nR > 1 ? (m.ShfR[m.nR - 1] - m.ShfR[0]) / (m.nR - 1) : 0.0;
+    const double dA = m.nA > 1 ? (m.ShfA[m.nA - 1] - m.ShfA[0]) / (m.nA - 1) : 0.0;
+    bool equi = true;
+    for (int k = 0; k < m.nR; k++) equi = equi && std::fabs(m.ShfR[0] + k * dR - m.ShfR[k]) < 1e-9;
+    for (int k = 0; k < m.nA; k++) equi = equi && std::fabs(m.ShfA[0] + k * dA - m.ShfA[k]) < 1e-9;
+    p.ShfR0 = (float)m.ShfR[0]; p.dShfR = (float)dR; p.ShfA0 = (float)m.ShfA[0]; p.dShfA = (float)dA;
+    p.equi = equi ? 1 : 0;
+  }
   if (aev_stride > 1024) { h->err = "AEV longer than 1024 is not supported"; return ANI_ERR_MODEL; }
   return ANI_OK;
 }

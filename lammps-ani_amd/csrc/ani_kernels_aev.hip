@@ -140,13 +140,26 @@ struct FastLds {
   float* gd;      // [3*kMaxAng] backward: dE/d(displacement) of the angular neighbours
   float* gt;      // [3*64] backward: staging of one chunk of radial-only gradients for the force scatter
   int* jt;        // [64]   ... and of their atom indices
+  int4* rowd;     // [2*64] backward: descriptors of 64 rows of the pair stream (build_row_descriptors)
+  float4* rowacc; // [2*64] backward, experiment ANI_PARK_ROWS only: per-row sums of the gradients w.r.t. the rows' neighbours
 };
 
+#ifdef ANI_PARK_ROWS
+constexpr int kParkWords = 512;
+#else
+constexpr int kParkWords = 0;
+#endif
+// lanes per row of the backward pair stream (a DPP quad): narrow rows waste few lanes on buckets of 5..12 columns
+#ifndef ANI_ROW_W
+#define ANI_ROW_W 16
+#endif
+constexpr int kRowW = ANI_ROW_W;
 __host__ __device__ constexpr int fast_wave_floats(int cap, bool bwd) {
   // both: ad 4*kMaxAng + afc kMaxAng + row kAevMax + tb kMaxBuckets*8 + starts 2*24
   // forward adds the phase-1 factor buffers pf (64*12) and r, fc per radial neighbour;
-  // backward adds aj, gd[3] per ANGULAR neighbour and the 4*64 staging words (the radial-only neighbours never touch LDS)
-  return 5 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? 4 * kMaxAng + 256 : 64 * 12 + 2 * cap);
+  // backward adds aj, gd[3] per ANGULAR neighbour, the 4*64 staging words (the radial-only neighbours never touch LDS)
+  // and the descriptors (8 words) of 64 rows of the pair stream at a time
+  return 5 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? 4 * kMaxAng + 256 + 512 + kParkWords : 64 * 12 + 2 * cap);
 }
 // same with the AEV row sized for the columns actually in use (rowf floats, multiple of 64)
 __host__ __device__ constexpr int fast_wave_floats_row(int cap, bool bwd, int rowf) {
@@ -174,6 +187,10 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
     L.gd = p; p += 3 * kMaxAng;
     L.gt = p; p += 3 * 64;
     L.jt = reinterpret_cast<int*>(p); p += 64;
+    L.rowd = reinterpret_cast<int4*>(p); p += 512;
+#ifdef ANI_PARK_ROWS
+    L.rowacc = reinterpret_cast<float4*>(p); p += 512;
+#endif
     L.row = p; p += rowf;
   }
   return L;
@@ -533,17 +550,20 @@ __device__ __forceinline__ float xor_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
   }
 }
-// Backward enumeration.  Every non-empty species-pair bucket is laid out as ROWS of 16 lanes (one DPP row each):
-//   s1 != s2 : row = neighbour of the species with fewer neighbours, column = neighbour of the other species;
+// Backward enumeration.  Every non-empty species-pair bucket is laid out as ROWS of kRowW lanes (4: one DPP quad):
+//   s1 != s2 : row = neighbour of one species, column = neighbour of the other, oriented so that the bucket needs the
+//              fewer rows of the stream;
 //   s1 == s2 : the strict upper triangle of n x n folded into nn/2 rows x nn columns (nn = n rounded up to even):
 //              lane (r, c) holds the pair (r, c) if c > r and the pair (nn-1-r, nn-1-c) if c < r;
-//   more than 16 columns: the row is cut into column blocks of 16, each its own row of the stream.
-// The rows of all buckets form one stream; a step of the pair loop takes 4 consecutive rows (64 lanes), whatever
-// buckets they belong to.  A pair's gradient with respect to its ROW neighbour is summed over the row with four DPP
-// adds (no LDS), lane 0 of the row adds the sum to that neighbour's LDS accumulator; the gradient with respect to the
-// COLUMN neighbour goes to its accumulator with one LDS float add per lane (at most ~4 lanes of an instruction
-// share an address).  The first version of this pass issued six LDS float atomics per pair with ~10-way address
-// conflicts, which cost more than all of its arithmetic.
+//   more than kRowW columns: the row is cut into column blocks of kRowW, each its own row of the stream.
+// The rows of all buckets form one stream; a step of the pair loop takes 64 / kRowW consecutive rows (64 lanes),
+// whatever buckets they belong to.  A pair's gradient with respect to its ROW neighbour is summed over the row with
+// DPP adds (no LDS), lane 0 of the row adds the sum to that neighbour's LDS accumulator; the gradient with respect to
+// the COLUMN neighbour goes to its accumulator with one LDS float add per lane.  Rows were 16 lanes wide at first: with
+// the 5..12 neighbours per species of a typical centre that left 40 % of the lanes of a step idle (water: 153 pairs in
+// 4 steps of 64); quads waste at most three lanes per row (the same 153 pairs in 3 steps), and the arithmetic of the
+// pairs, not the bookkeeping around it, is what this pass spends its time on.  (The very first version issued six LDS
+// float atomics per pair with ~10-way address conflicts, which cost more than all of its arithmetic.)
 // entry: {row0, ra, nr, ca, nc, outoff, tri, column blocks}.  Returns the number of rows in the stream.
 template <int NA, int NZ>
 __device__ __forceinline__ int build_row_table(const AevParams& p, int lane, FastLds& L, int& nbk) {
@@ -562,13 +582,14 @@ __device__ __forceinline__ int build_row_table(const AevParams& p, int lane, Fas
       const int nn = (n1 + 1) & ~1;
       if (n1 >= 2) { nrows = nn >> 1; ncols = nn; }
     } else if (n1 > 0 && n2 > 0) {
-      const bool sw = n1 > n2;   // fewer rows, wider rows
+      // the orientation that takes fewer rows of kRowW lanes
+      const bool sw = n2 * ((n1 + kRowW - 1) / kRowW) < n1 * ((n2 + kRowW - 1) / kRowW);
       ra = sw ? a2 : a1; nr = sw ? n2 : n1;
       ca = sw ? a1 : a2; nc = sw ? n1 : n2;
       nrows = nr; ncols = nc;
     }
     if (nrows > 0) {
-      ncb = (ncols + 15) >> 4;
+      ncb = (ncols + kRowW - 1) / kRowW;
       nrow = nrows * ncb;
     }
   }
@@ -581,6 +602,37 @@ __device__ __forceinline__ int build_row_table(const AevParams& p, int lane, Fas
   }
   nbk = __popcll(m);
   return __builtin_amdgcn_readlane(incl, 63);
+}
+
+// Descriptors of rows RB .. RB+63 of the backward pair stream, one lane per row, so that the per-pair lanes of a step
+// (4 rows x 16 lanes) read what they need about their row with two 16-byte LDS loads instead of each repeating the
+// bucket search, the division by the column-block count and the fold arithmetic (that prologue was ~90 of the ~480
+// vector instructions of a step):
+//   d0 = {row neighbour of the pairs above the diagonal (all pairs of a rectangular bucket), row neighbour of the folded
+//         pairs below it (-1: none), first column neighbour of the bucket, number of columns}
+//   d1 = {first column of this row's block, r | tri << 16 | valid << 17, nn (columns of the folded triangle), offset of
+//         the bucket's dE/dAEV block}
+constexpr int kRowBlock = 64;
+__device__ __forceinline__ void build_row_descriptors(FastLds& L, int nbk, int nrows_stream, int RB, int lane) {
+  const int R = RB + lane;
+  int4 d0 = make_int4(0, -1, 0, 0), d1 = make_int4(0, 0, 0, 0);
+  if (R < nrows_stream) {
+    int e = 0;
+    for (int k = 1; k < nbk; k++)
+      if (R >= L.tb[8 * k]) e = k;
+    const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);       // row0, ra, nr, ca
+    const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);   // nc, outoff, tri, ncb
+    const int u = R - e0.x;
+    const int r = e1.w > 1 ? u / e1.w : u;
+    const int nn = (e0.z + 1) & ~1;
+    const int rb = nn - 1 - r;
+    d0 = make_int4(e0.y + r, (e1.z && rb < e0.z) ? e0.y + rb : -1, e0.w, e1.x);
+    d1 = make_int4((u - r * e1.w) * kRowW, r | (e1.z ? 1 << 16 : 0) | (1 << 17), nn, e1.y);
+  }
+  if (lane < kRowBlock) {
+    L.rowd[2 * lane] = d0;
+    L.rowd[2 * lane + 1] = d1;
+  }
 }
 
 template <int NA, int NZ, int NCH, typename Hook>
@@ -596,7 +648,7 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
 #ifndef ABLF_NO_RAD
   {
     const int q = lane >> 4, k = lane & 15;
-    const float shf = p.ShfR[k];
+    const float shf = fmaf((float)k, p.dShfR, p.ShfR0);
     const float c = -p.EtaR * kLog2e;
     for (int s = 0; s < p.S; s++) {
       const int b0 = L.rstart[s], b1 = L.rstart[s + 1];
@@ -674,10 +726,11 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
         const float basez = fmaxf(0.5f * (1.f + cth * p.cosZ[z] + sth * p.sinZ[z]), 0.f);
         t1[z] = w * fexp2(p.Zeta * flog2(basez));
       }
+      float dr = rho - p.ShfA0;   // equidistant shifts: one subtraction per step instead of a table of NA scalars
 #pragma unroll
       for (int s = 0; s < NA; s++) {
-        const float dr = rho - p.ShfA[s];
         t2[s] = fexp2(cA * dr * dr);
+        dr -= p.dShfA;
       }
 #pragma unroll
       for (int z = 0; z < NZ; z += 4)
@@ -839,15 +892,16 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       const float fc = 0.5f * fcos_rev(r * rev) + 0.5f;
       const float dfc = -0.5f * p.pi_over_Rcr * fsin_rev(r * rev);
       float dEdr = 0.f;
+      float dr = r - p.ShfR0;   // equidistant shifts
 #pragma unroll
       for (int k4 = 0; k4 < NR / 4; k4++) {
         const float4 gv = gg4[k4];
         const float gk[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-          const float dr = r - p.ShfR[4 * k4 + kk];
           const float e = fexp2(cR * dr * dr);
           dEdr = fmaf(gk[kk] * e, fmaf(-2.f * p.EtaR * dr, fc, dfc), dEdr);
+          dr -= p.dShfR;
         }
       }
       const float sc = 0.25f * dEdr * frcp(r);
@@ -908,28 +962,24 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   // ---- angular: lane = pair; 4 rows of the stream per step (see build_row_table) ----
   const float cA = -p.EtaA * kLog2e;
 #ifdef ABL_NO_ANG
-  for (int R0 = 0; R0 < 0; R0 += 4) {
+  for (int RB = 0; RB < 0; RB += kRowBlock) {
 #else
-  for (int R0 = 0; R0 < nrows_stream; R0 += 4) {
+  for (int RB = 0; RB < nrows_stream; RB += kRowBlock) {
 #endif
-    const int R = R0 + (lane >> 4);
-    const bool row_ok = R < nrows_stream;
-    int e = 0;
-    for (int k = 1; k < nbk; k++)
-      if (R >= L.tb[8 * k]) e = k;
-    const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);   // row0, ra, nr, ca
-    const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);   // nc, outoff, tri, ncb
-    const bool tri = e1.z != 0;
-    const int u = R - e0.x;
-    const int r = e1.w > 1 ? u / e1.w : u;
-    const int col = ((u - r * e1.w) << 4) + (lane & 15);
-    const int nn = (e0.z + 1) & ~1;
+   build_row_descriptors(L, nbk, nrows_stream, RB, lane);
+   wave_sync();
+   for (int R0 = RB; R0 < min(RB + kRowBlock, nrows_stream); R0 += 64 / kRowW) {
+    const int rl = R0 - RB + lane / kRowW;
+    const int4 d0 = L.rowd[2 * rl], d1 = L.rowd[2 * rl + 1];
+    const bool row_ok = (d1.y >> 17) & 1, tri = (d1.y >> 16) & 1;
+    const int r = d1.y & 0xffff, nn = d1.z;
+    const int col = d1.x + lane % kRowW;
     const bool above = !tri || col > r;   // tri: which of the two folded pairs this lane holds
-    const int a = above ? r : nn - 1 - r;
     const int b = above ? col : nn - 1 - col;
-    const bool valid = row_ok && b < e1.x && (!tri || col != r);
-    const int ia = e0.y + (valid ? a : 0);
-    const int ib = e0.w + (valid ? b : (tri ? 1 : 0));   // masked lanes: distinct neighbours keep the geometry finite
+    const bool valid = row_ok && b < d0.w && (!tri || col != r) && (above || d0.y >= 0);
+    // masked lanes: two distinct neighbours keep the geometry finite
+    const int ia = (valid && !above) ? d0.y : d0.x;
+    const int ib = d0.z + (valid ? b : ((tri && r == 0) ? 1 : 0));
     const float4 A = L.ad[ia], B = L.ad[ib];
     const float inv_ra = frcp(A.w), inv_rb = frcp(B.w);
     const float inv_rr = inv_ra * inv_rb;
@@ -950,11 +1000,18 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       f1[z] = pm1 * bz;
       df1[z] = p.Zeta * pm1 * 0.5f * (sn * p.cosZ[z] - c * p.sinZ[z]) * inv_s;
     }
-    const float4* gg4 = reinterpret_cast<const float4*>(L.row + e1.y);  // outoff is a multiple of NA*NZ
+    const float4* gg4 = reinterpret_cast<const float4*>(L.row + d1.w);  // outoff is a multiple of NA*NZ
     float Aq = 0.f, Bq = 0.f, Cq = 0.f;
+    float drA = rho - p.ShfA0;
 #pragma unroll
     for (int sa = 0; sa < NA; sa++) {
-      const float dr = rho - p.ShfA[sa];
+#ifdef ANI_GG_SPLIT
+      // keep the compiler from loading all NA x NZ dE/dAEV values of the bucket before the first is used (32 registers):
+      // the second half of the shifts is fetched after the first half has been contracted
+      if (sa == NA / 2) asm volatile("" ::: "memory");
+#endif
+      const float dr = drA;
+      drA -= p.dShfA;   // equidistant shifts
       const float f2 = fexp2(cA * dr * dr);
       const float df2 = -2.f * p.EtaA * dr * f2;
       float g1 = 0.f, gd1 = 0.f;
@@ -982,31 +1039,95 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     const float vb[3] = {cc * A.x + tb * B.x, cc * A.y + tb * B.y, cc * A.z + tb * B.z};  // d/d(neighbour ib)
 #ifndef ABL_NO_LATOM
     // column neighbour: one LDS add per lane and component
+#ifndef ABL_NO_COLADD
+#if ANI_ROW_W == 16 && defined(ANI_COLREDUCE)   // measured slower: the extra live values spill (128-VGPR budget)
+    // A ds_add_f32 whose lanes hit the same address is serialised per address, and the four rows of a step that belong to
+    // the same bucket and column block share their 16 columns: a 4-way conflict on every column add, ~2/3 of the LDS
+    // time of this pass.  Such a step (wave-uniform test on the rows' keys) sums the four rows in registers first -- two
+    // row / half-wave swaps per value -- and lets ONE row of lanes add, conflict-free.  cA: pairs whose column neighbour
+    // is `col` (all pairs of a rectangular bucket, the above-diagonal ones of a folded triangle); cB: the
+    // below-diagonal ones, whose column neighbour is nn-1-col.
+    const int key = row_ok ? ((d1.w << 8) | (d1.x >> 4)) : -1;   // bucket (its output offset) and column block
+    const int k0 = __builtin_amdgcn_readlane(key, 0), k1 = __builtin_amdgcn_readlane(key, 16),
+              k2 = __builtin_amdgcn_readlane(key, 32), k3 = __builtin_amdgcn_readlane(key, 48);
+    if ((k1 == k0 || k1 < 0) && (k2 == k0 || k2 < 0) && (k3 == k0 || k3 < 0)) {   // wave-uniform
+      const bool tri0 = __builtin_amdgcn_readlane(d1.y, 0) & (1 << 16);
+      float cA[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) cA[k] = xor_sum<32>(xor_sum<16>((valid && above) ? vb[k] : 0.f));
+      if (lane < 16 && col < d0.w) {
+        const int q = d0.z + col;
+        TILE_ADD(&L.gd[3 * q], cA[0]); TILE_ADD(&L.gd[3 * q + 1], cA[1]); TILE_ADD(&L.gd[3 * q + 2], cA[2]);
+      }
+      if (tri0) {
+        float cB[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) cB[k] = xor_sum<32>(xor_sum<16>((valid && !above) ? vb[k] : 0.f));
+        const int colB = nn - 1 - col;
+        if (lane < 16 && colB >= 0 && colB < d0.w) {
+          const int q = d0.z + colB;
+          TILE_ADD(&L.gd[3 * q], cB[0]); TILE_ADD(&L.gd[3 * q + 1], cB[1]); TILE_ADD(&L.gd[3 * q + 2], cB[2]);
+        }
+      }
+    } else
+#endif
     if (valid) {   // angular list index = index of the LDS accumulators
       TILE_ADD(&L.gd[3 * ib], vb[0]); TILE_ADD(&L.gd[3 * ib + 1], vb[1]); TILE_ADD(&L.gd[3 * ib + 2], vb[2]);
     }
+#else
+    asm volatile("" ::"v"(vb[0]), "v"(vb[1]), "v"(vb[2]));
+#endif
     // row neighbour(s): sums over the 16 lanes of the row, [0..2] for the pairs whose ia is r (all pairs of a
     // rectangular bucket, the above-diagonal ones of a folded triangle), [3..5] for those whose ia is nn-1-r
     float rw[6];
 #pragma unroll
     for (int k = 0; k < 3; k++) { rw[k] = above ? va[k] : 0.f; rw[3 + k] = above ? 0.f : va[k]; }
+#ifndef ABL_NO_ROWDPP
 #pragma unroll
-    for (int k = 0; k < 6; k++) rw[k] = xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(rw[k]))));
-    if ((lane & 15) == 0 && row_ok) {
-      if (r < e0.z) {
-        const int q = e0.y + r;
+    for (int k = 0; k < 6; k++) {
+      rw[k] = xor_sum<2>(xor_sum<1>(rw[k]));
+      if constexpr (kRowW >= 8) rw[k] = xor_sum<4>(rw[k]);
+      if constexpr (kRowW >= 16) rw[k] = xor_sum<8>(rw[k]);
+    }
+#endif
+#ifdef ANI_PARK_ROWS
+    // experiment (slower, kept for the record): row sums parked per row and added once per block of rows
+    if (lane % kRowW == 0) {
+      L.rowacc[2 * rl] = make_float4(rw[0], rw[1], rw[2], 0.f);
+      L.rowacc[2 * rl + 1] = make_float4(rw[3], rw[4], rw[5], 0.f);
+    }
+#elif !defined(ABL_NO_ROWADD)
+    if (lane % kRowW == 0 && row_ok) {
+      {
+        const int q = d0.x;
         TILE_ADD(&L.gd[3 * q], rw[0]); TILE_ADD(&L.gd[3 * q + 1], rw[1]); TILE_ADD(&L.gd[3 * q + 2], rw[2]);
       }
-      if (tri && nn - 1 - r < e0.z) {
-        const int q = e0.y + nn - 1 - r;
+      if (d0.y >= 0) {
+        const int q = d0.y;
         TILE_ADD(&L.gd[3 * q], rw[3]); TILE_ADD(&L.gd[3 * q + 1], rw[4]); TILE_ADD(&L.gd[3 * q + 2], rw[5]);
       }
     }
 #else
+    asm volatile("" ::"v"(rw[0]), "v"(rw[1]), "v"(rw[2]), "v"(rw[3]), "v"(rw[4]), "v"(rw[5]));
+#endif
+#else
     asm volatile("" ::"v"(va[0]), "v"(va[1]), "v"(va[2]), "v"(vb[0]), "v"(vb[1]), "v"(vb[2]));
 #endif
+   }
+   wave_sync();
+#if defined(ANI_PARK_ROWS) && !defined(ABL_NO_LATOM)
+   if (lane < kRowBlock && RB + lane < nrows_stream) {   // row sums -> accumulators of the rows' neighbours
+     const int4 d0 = L.rowd[2 * lane];
+     const float4 sa = L.rowacc[2 * lane];
+     TILE_ADD(&L.gd[3 * d0.x], sa.x); TILE_ADD(&L.gd[3 * d0.x + 1], sa.y); TILE_ADD(&L.gd[3 * d0.x + 2], sa.z);
+     if (d0.y >= 0) {
+       const float4 sb = L.rowacc[2 * lane + 1];
+       TILE_ADD(&L.gd[3 * d0.y], sb.x); TILE_ADD(&L.gd[3 * d0.y + 1], sb.y); TILE_ADD(&L.gd[3 * d0.y + 2], sb.z);
+     }
+   }
+#endif
+   wave_sync();   // the tables are rewritten by the next block of rows; after the last block: gd is complete
   }
-  wave_sync();
 
   // ---- the angular neighbours: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d ----
   before_final_scatter();   // the next centre's prefetch is secured before these atomics enter the vmcnt queue
@@ -1289,7 +1410,7 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_generic(AevParams p,
 // launchers
 // =====================================================================================================
 static int fast_kind(const AevParams& p) {
-  if (p.nR != 16 || p.S > 8 || (p.aev_stride & 3)) return 0;
+  if (p.nR != 16 || p.S > 8 || (p.aev_stride & 3) || !p.equi) return 0;
   if (p.nA == 8 && p.nZ == 4) return 1;
   if (p.nA == 4 && p.nZ == 8) return 2;
   return 0;
@@ -1300,13 +1421,16 @@ static int fast_kind(const AevParams& p) {
 // 7.1 A list) 37 % of a uniform neighbourhood -- so 3/4 of the longest list (at least 128 slots) is reserved instead of
 // all of it; the smaller LDS slice is what lets more waves share a CU.  A centre that still overflows raises the
 // capacity error like any other overflow (never a silent truncation), and AevParams::full_cap restores the full size.
+#ifndef ANI_CAP_GRAIN
+#define ANI_CAP_GRAIN 64
+#endif
 static int radial_cap(const AevParams& p, int max_numneigh) {
   int full = (max_numneigh + 63) / 64 * 64;
   if (full < 64) full = 64;
   if (p.compat || p.full_cap) return full;
   int est = (3 * max_numneigh + 3) / 4;
   if (est < 128) est = 128;
-  est = (est + 63) / 64 * 64;
+  est = (est + ANI_CAP_GRAIN - 1) / ANI_CAP_GRAIN * ANI_CAP_GRAIN;
   return est < full ? est : full;
 }
 

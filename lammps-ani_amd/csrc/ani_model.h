@@ -40,6 +40,11 @@ struct AevParams {
   int compat;  // 1: no radial screening ("pyaev"), 0: r <= Rcr ("cuaev")
   int full_cap;  // 1: size the radial LDS list for the longest neighbour list even when screened (ani_set_option)
   float Rcr, Rca, EtaR, EtaA, Zeta, pi_over_Rcr, pi_over_Rca;
+  // equidistant shift grids (every ANI model): ShfR[k] = ShfR0 + k dShfR, ShfA[k] = ShfA0 + k dShfA.  The fast kernels use
+  // these four numbers instead of the tables (24 scalar registers less in kernels that run out of them); equi = 0 sends
+  // a model with irregular grids to the generic kernels
+  float ShfR0, dShfR, ShfA0, dShfA;
+  int equi;
   float ShfR[kMaxShfR], ShfA[kMaxShfA], cosZ[kMaxShfZ], sinZ[kMaxShfZ];
 };
 

@@ -7,7 +7,7 @@ OBJS="ani_hip.o ani_model.o ani_kernels_mlp.o ani_kernels_misc.o ani_kernels_f64
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   ( hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result $flags -c ani_kernels_aev.hip -o ../../tools/abl/aev_$name.o &&
-    hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/abl/libani_$name.so $OBJS ../../tools/abl/aev_$name.o && echo built $name ) &
+    hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/abl/libani_$name.so $OBJS ../../tools/abl/aev_$name.o -L/opt/rocm/lib -lrocprofiler-sdk-roctx -Wl,-rpath,/opt/rocm/lib && echo built $name ) &
   while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 0.5; done
 done
 wait
