@@ -276,7 +276,7 @@ def main():
         ani.set_option("prune_absent_species", 1)
     dt_hot, ph_hot = wl.timed_run(args.steps, args.warmup)
     energy_local = float(wl.d_ev[0].item())
-    if not np.isfinite(energy_local):
+    if not np.isfinite(energy_local) and not os.environ.get("ANI_BENCH_ALLOW_NAN"):   # the variable: timing-only ablation builds
         raise SystemExit("non-finite energy: LDS neighbour capacity exceeded or numerical failure")
     aev_cols = ani.debug_view().aev_active_length  # columns of the species present (1008 when all 7 occur)
 

@@ -60,12 +60,21 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
   return v;
 }
+#ifdef ABL_FAKE_TRANS   // timing experiment only (wrong results): every transcendental replaced by one multiply-add
+__device__ __forceinline__ float fexp2(float x) { return fmaf(x, 0.001f, 1.0f); }
+__device__ __forceinline__ float flog2(float x) { return fmaf(x, 0.5f, -0.5f); }
+__device__ __forceinline__ float frcp(float x) { return fmaf(x, -0.1f, 1.0f); }
+__device__ __forceinline__ float frsq(float x) { return fmaf(x, -0.1f, 1.0f); }
+__device__ __forceinline__ float fcos_rev(float rev) { return fmaf(rev, -0.5f, 1.0f); }
+__device__ __forceinline__ float fsin_rev(float rev) { return fmaf(rev, 0.5f, 0.1f); }
+#else
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fcos_rev(float rev) { return __builtin_amdgcn_cosf(rev); }  // cos(2 pi rev)
 __device__ __forceinline__ float fsin_rev(float rev) { return __builtin_amdgcn_sinf(rev); }
+#endif
 constexpr float kLog2e = 1.4426950408889634f;
 
 // unordered pair index t -> (a, b), a < b < n, row-major over the strict upper triangle
@@ -140,12 +149,12 @@ struct FastLds {
   float* gd;      // [3*kMaxAng] backward: dE/d(displacement) of the angular neighbours
   float* gt;      // [3*64] backward: staging of one chunk of radial-only gradients for the force scatter
   int* jt;        // [64]   ... and of their atom indices
-  int4* rowd;     // [2*64] backward: descriptors of 64 rows of the pair stream (build_row_descriptors)
+  int4* rowd;     // [2*32] backward: descriptors of 32 rows of the pair stream (build_row_descriptors)
   float4* rowacc; // [2*64] backward, experiment ANI_PARK_ROWS only: per-row sums of the gradients w.r.t. the rows' neighbours
 };
 
 #ifdef ANI_PARK_ROWS
-constexpr int kParkWords = 512;
+constexpr int kParkWords = 256;
 #else
 constexpr int kParkWords = 0;
 #endif
@@ -158,8 +167,8 @@ __host__ __device__ constexpr int fast_wave_floats(int cap, bool bwd) {
   // both: ad 4*kMaxAng + afc kMaxAng + row kAevMax + tb kMaxBuckets*8 + starts 2*24
   // forward adds the phase-1 factor buffers pf (64*12) and r, fc per radial neighbour;
   // backward adds aj, gd[3] per ANGULAR neighbour, the 4*64 staging words (the radial-only neighbours never touch LDS)
-  // and the descriptors (8 words) of 64 rows of the pair stream at a time
-  return 5 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? 4 * kMaxAng + 256 + 512 + kParkWords : 64 * 12 + 2 * cap);
+  // and the descriptors (8 words) of 32 rows of the pair stream at a time
+  return 5 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? 4 * kMaxAng + 256 + 256 + kParkWords : 64 * 12 + 2 * cap);
 }
 // same with the AEV row sized for the columns actually in use (rowf floats, multiple of 64)
 __host__ __device__ constexpr int fast_wave_floats_row(int cap, bool bwd, int rowf) {
@@ -187,9 +196,9 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
     L.gd = p; p += 3 * kMaxAng;
     L.gt = p; p += 3 * 64;
     L.jt = reinterpret_cast<int*>(p); p += 64;
-    L.rowd = reinterpret_cast<int4*>(p); p += 512;
+    L.rowd = reinterpret_cast<int4*>(p); p += 256;
 #ifdef ANI_PARK_ROWS
-    L.rowacc = reinterpret_cast<float4*>(p); p += 512;
+    L.rowacc = reinterpret_cast<float4*>(p); p += 256;
 #endif
     L.row = p; p += rowf;
   }
@@ -332,11 +341,10 @@ __global__ __launch_bounds__(64 * kWavesC, NCH >= 4 ? 4 : 5) void nbr_compact_ke
   }
 }
 
-// What the forward / backward kernels prefetch for a centre, all addressed by its row alone (no dependent loads): the
-// header (per-lane copies; made scalar when the centre is started), slots 0..63 of the angular region, the first NCH
-// 64-entry chunks of the radial-only region (entries past the counts are stale memory, masked by the consumer) and,
-// for the backward pass, the atom indices and the dE/dAEV row.  Issued one centre ahead; the consumer touch()es all of
-// it before it issues its own stores / atomics (vmcnt is in-order: see nbr_compact_kernel).
+// What the forward / backward kernels load for a centre, all addressed by its row alone (no dependent loads): the
+// header (per-lane copies; made scalar once arrived), slots 0..63 of the angular region, the first NCH 64-entry chunks
+// of the radial-only region (entries past the counts are stale memory, masked by the consumer) and, for the backward
+// pass, the atom indices and the dE/dAEV row.
 typedef int hdr_t __attribute__((ext_vector_type(8)));
 template <int NCH, bool BWD, int GR>
 struct Prefetched {
@@ -604,7 +612,7 @@ __device__ __forceinline__ int build_row_table(const AevParams& p, int lane, Fas
   return __builtin_amdgcn_readlane(incl, 63);
 }
 
-// Descriptors of rows RB .. RB+63 of the backward pair stream, one lane per row, so that the per-pair lanes of a step
+// Descriptors of rows RB .. RB+31 of the backward pair stream, one lane per row, so that the per-pair lanes of a step
 // (4 rows x 16 lanes) read what they need about their row with two 16-byte LDS loads instead of each repeating the
 // bucket search, the division by the column-block count and the fold arithmetic (that prologue was ~90 of the ~480
 // vector instructions of a step):
@@ -612,7 +620,7 @@ __device__ __forceinline__ int build_row_table(const AevParams& p, int lane, Fas
 //         pairs below it (-1: none), first column neighbour of the bucket, number of columns}
 //   d1 = {first column of this row's block, r | tri << 16 | valid << 17, nn (columns of the folded triangle), offset of
 //         the bucket's dE/dAEV block}
-constexpr int kRowBlock = 64;
+constexpr int kRowBlock = 32;   // rows of the pair stream whose descriptors are held at a time
 __device__ __forceinline__ void build_row_descriptors(FastLds& L, int nbk, int nrows_stream, int RB, int lane) {
   const int R = RB + lane;
   int4 d0 = make_int4(0, -1, 0, 0), d1 = make_int4(0, 0, 0, 0);
@@ -635,9 +643,9 @@ __device__ __forceinline__ void build_row_descriptors(FastLds& L, int nbk, int n
   }
 }
 
-template <int NA, int NZ, int NCH, typename Hook>
+template <int NA, int NZ, int NCH>
 __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
-                                               const Prefetched<NCH, false, 1>& pf, int lane, Hook&& before_stores) {
+                                               const Prefetched<NCH, false, 1>& pf, int lane) {
   constexpr int NR = 16, Q = 64 / NA;
   for (int e = lane; e < (p.aev_stride >> 2); e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
   int nrad, nang;
@@ -775,45 +783,26 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
   flush();
   wave_sync();
 
-  before_stores();   // the next centre's prefetch is secured before this centre's stores enter the vmcnt queue
   float4* dst = reinterpret_cast<float4*>(a.aev + (long long)row * p.aev_stride);
   const int n4 = p.aev_stride >> 2;
   for (int e = lane; e < n4; e += 64) dst[e] = reinterpret_cast<const float4*>(L.row)[e];
   wave_sync();  // the LDS slice is reused by this wave's next centre
 }
 
-// Persistent waves: wave w handles rows w, w + W, w + 2W, ...; the inputs of centre c+1 are requested when centre c is
-// started and secured (touch_prefetch + the scalar copy of its header) right before centre c issues its stores /
-// atomics.  Two prefetch stages used alternately (the loop body is written out twice): a `cur = nxt` copy lets the
-// compiler move parts of it up to the loads, which then wait for them on the spot.
+// Persistent waves: wave w handles rows w, w + W, w + 2W, ...  A centre's inputs (header, list chunks, dE/dAEV row: all
+// addressed by the row alone) are requested when the centre is started and waited for on the spot: the kernels are
+// bound by what their resident waves execute, not by one wave's latency, so the other waves cover the wait.  Requesting
+// them one centre ahead (two register stages used alternately, secured before the centre's stores and atomics entered
+// the in-order vmcnt queue) was built and measured: forward unchanged, backward 4 % SLOWER -- the second stage costs
+// 22 registers that the pair loop uses better.
 #define ANI_PERSISTENT_LOOP(KW, NCH, BWD, GR, CENTRE)                                                      \
   const int nw = gridDim.x * KW;                                                                          \
-  int row = blockIdx.x * KW + wave;                                                                       \
-  if (row >= a.nrows) return;                                                                             \
-  Prefetched<NCH, BWD, GR> sA, sB;                                                                        \
-  hdr_t hA, hB;                                                                                           \
-  issue_prefetch(p, a, row, lane, sA);                                                                    \
-  touch_prefetch(sA);                                                                                     \
-  hA = scalar_header(a, row, sA);                                                                         \
-  while (true) {                                                                                          \
-    {                                                                                                     \
-      issue_prefetch(p, a, row + nw, lane, sB);                                                           \
-      auto secure = [&]() { touch_prefetch(sB); hB = scalar_header(a, row + nw, sB); };                  \
-      const hdr_t& hc = hA;                                                                               \
-      const Prefetched<NCH, BWD, GR>& cur = sA;                                                           \
-      if (hc[0] >= 0) { CENTRE; } else { secure(); }                                                      \
-      row += nw;                                                                                          \
-      if (row >= a.nrows) break;                                                                          \
-    }                                                                                                     \
-    {                                                                                                     \
-      issue_prefetch(p, a, row + nw, lane, sA);                                                           \
-      auto secure = [&]() { touch_prefetch(sA); hA = scalar_header(a, row + nw, sA); };                  \
-      const hdr_t& hc = hB;                                                                               \
-      const Prefetched<NCH, BWD, GR>& cur = sB;                                                           \
-      if (hc[0] >= 0) { CENTRE; } else { secure(); }                                                      \
-      row += nw;                                                                                          \
-      if (row >= a.nrows) break;                                                                          \
-    }                                                                                                     \
+  for (int row = blockIdx.x * KW + wave; row < a.nrows; row += nw) {                                      \
+    Prefetched<NCH, BWD, GR> cur;                                                                         \
+    issue_prefetch(p, a, row, lane, cur);                                                                 \
+    touch_prefetch(cur);                                                                                  \
+    const hdr_t hc = scalar_header(a, row, cur);                                                          \
+    if (hc[0] >= 0) { CENTRE; }                                                                           \
   }
 
 template <int NA, int NZ, int NCH>
@@ -821,7 +810,7 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FWD_MINW) void aev_forward_fast(Ae
   extern __shared__ float4 smem4[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, false, rowf), cap, false, rowf);
-  ANI_PERSISTENT_LOOP(kWaves, NCH, false, 1, (forward_centre<NA, NZ, NCH>(p, a, L, row, hc, cur, lane, secure)))
+  ANI_PERSISTENT_LOOP(kWaves, NCH, false, 1, (forward_centre<NA, NZ, NCH>(p, a, L, row, hc, cur, lane)))
 }
 
 // coalesced force scatter of `cnt` neighbours whose gradients sit in LDS as g[3*q + k] with atom indices jx[q]:
@@ -838,10 +827,10 @@ __device__ __forceinline__ void scatter_neighbours(const AevArgs& a, const float
 #endif
 }
 
-template <int NA, int NZ, int NCH, int GR, bool VIR, typename Hook>
+template <int NA, int NZ, int NCH, int GR, bool VIR>
 __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
                                                 const Prefetched<NCH, true, GR>& pf, int lane, float (&wv)[9],
-                                                const RepTab& rep, float& er, Hook&& before_final_scatter) {
+                                                const RepTab& rep, float& er) {
   constexpr int NR = 16;
   const int centre = h[0];
 #pragma unroll
@@ -937,7 +926,9 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       L.aj[t] = j;
       L.gd[3 * t] = gx; L.gd[3 * t + 1] = gy; L.gd[3 * t + 2] = gz;
     }
-    // radial-only neighbours: finished here
+    // radial-only neighbours: finished here (scattered at once; ONE merged scatter per centre -- angular + radial-only +
+    // centre, 21 atoms per atomic instruction instead of 16 -- was measured: 5 % slower, the atomics then leave in one
+    // burst at the end of the centre instead of two spread over it)
     if (!ang) {   // wave-uniform
       const int lo = 0, hi = min(nr2 - 64 * c, 64);
       if (live) {
@@ -1040,7 +1031,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
 #ifndef ABL_NO_LATOM
     // column neighbour: one LDS add per lane and component
 #ifndef ABL_NO_COLADD
-#if ANI_ROW_W == 16 && defined(ANI_COLREDUCE)   // measured slower: the extra live values spill (128-VGPR budget)
+#if ANI_ROW_W == 16 && defined(ANI_COLREDUCE)   // measured slower (0.434 against 0.407 ms with registers to spare, worse when it spills)
     // A ds_add_f32 whose lanes hit the same address is serialised per address, and the four rows of a step that belong to
     // the same bucket and column block share their 16 columns: a 4-way conflict on every column add, ~2/3 of the LDS
     // time of this pass.  Such a step (wave-uniform test on the rows' keys) sums the four rows in registers first -- two
@@ -1130,7 +1121,6 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   }
 
   // ---- the angular neighbours: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d ----
-  before_final_scatter();   // the next centre's prefetch is secured before these atomics enter the vmcnt queue
   for (int q = lane; q < nang; q += 64) {
     const float gx = L.gd[3 * q], gy = L.gd[3 * q + 1], gz = L.gd[3 * q + 2];
     fx += gx; fy += gy; fz += gz;
@@ -1160,7 +1150,7 @@ __global__ __launch_bounds__(64 * kWavesB, ANI_BWD_MINW) void aev_backward_fast(
   float wv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this lane's share of the wave's virial
   float er = 0.f;                                                // ... and of its repulsion energy
   ANI_PERSISTENT_LOOP(kWavesB, NCH, true, GR,
-                      (backward_centre<NA, NZ, NCH, GR, VIR>(p, a, L, row, hc, cur, lane, wv, rep, er, secure)))
+                      (backward_centre<NA, NZ, NCH, GR, VIR>(p, a, L, row, hc, cur, lane, wv, rep, er)))
   if (rep.on) {
     double se = (double)er;
 #pragma unroll
@@ -1430,7 +1420,7 @@ static int radial_cap(const AevParams& p, int max_numneigh) {
   if (p.compat || p.full_cap) return full;
   int est = (3 * max_numneigh + 3) / 4;
   if (est < 128) est = 128;
-  est = (est + ANI_CAP_GRAIN - 1) / ANI_CAP_GRAIN * ANI_CAP_GRAIN;
+  est = (est + ANI_CAP_GRAIN - 1) / ANI_CAP_GRAIN * ANI_CAP_GRAIN;   // 32 (a fifth forward workgroup per CU) measured slower: 0.246 against 0.230 ms
   return est < full ? est : full;
 }
 
