@@ -341,63 +341,47 @@ __global__ __launch_bounds__(64 * kWavesC, NCH >= 4 ? 4 : 5) void nbr_compact_ke
   }
 }
 
-// What the forward / backward kernels load for a centre, all addressed by its row alone (no dependent loads): the
-// header (per-lane copies; made scalar once arrived), slots 0..63 of the angular region, the first NCH 64-entry chunks
-// of the radial-only region (entries past the counts are stale memory, masked by the consumer) and, for the backward
-// pass, the atom indices and the dE/dAEV row.
+// What the forward / backward kernels load for a centre: first the header (wave-uniform, two 16-byte words), then the
+// first NCH 64-entry chunks of its compact list in slot order -- slots [0, nang) are the angular region, slots
+// [nang, nrad) the radial-only one -- so that a typical centre (nrad < 64) is ONE chunk with every lane busy instead
+// of an angular chunk (a quarter of the lanes) and a radial-only chunk; for the backward pass also the atom indices and
+// the dE/dAEV row.  No prefetch across centres (see ANI_PERSISTENT_LOOP).
 typedef int hdr_t __attribute__((ext_vector_type(8)));
 template <int NCH, bool BWD, int GR>
-struct Prefetched {
-  int4 h0, h1;
-  float4 xa, xr[NCH];
-  int ja, jr[BWD ? NCH : 1];
+struct Loaded {
+  float4 xx[NCH];
+  int jj[BWD ? NCH : 1];
   float4 grow[BWD ? GR : 1];
 };
+__device__ __forceinline__ hdr_t load_header(const AevArgs& a, int row) {   // row is wave-uniform
+  const int4* hp = a.cl_hdr + 2 * (size_t)row;
+  const int4 h0 = hp[0], h1 = hp[1];
+  hdr_t h;
+  h[0] = __builtin_amdgcn_readfirstlane(h0.x); h[1] = __builtin_amdgcn_readfirstlane(h0.y);
+  h[2] = __builtin_amdgcn_readfirstlane(h0.z); h[3] = __builtin_amdgcn_readfirstlane(h0.w);
+  h[4] = __builtin_amdgcn_readfirstlane(h1.x); h[5] = __builtin_amdgcn_readfirstlane(h1.y);
+  h[6] = __builtin_amdgcn_readfirstlane(h1.z); h[7] = __builtin_amdgcn_readfirstlane(h1.w);
+  return h;
+}
+// compact-list slot t (angular entries first, then the radial-only ones) -> index in the row's cl_xyz / cl_j
+__device__ __forceinline__ int slot_index(int t, int nang) { return t < nang ? t : kMaxAng + (t - nang); }
 template <int NCH, bool BWD, int GR>
-__device__ __forceinline__ void issue_prefetch(const AevParams& p, const AevArgs& a, int row, int lane, Prefetched<NCH, BWD, GR>& pf) {
-  const int rc = opaque(row < a.nrows ? row : a.nrows - 1);
-  const int4* hp = a.cl_hdr + 2 * (size_t)rc;
-  pf.h0 = hp[0];
-  pf.h1 = hp[1];
-  const float4* px = a.cl_xyz + (size_t)rc * a.cl_stride;
-  const int* pj = a.cl_j + (size_t)rc * a.cl_stride;
-  pf.xa = px[lane];
-  if constexpr (BWD) pf.ja = pj[lane];
+__device__ __forceinline__ void load_lists(const AevParams& p, const AevArgs& a, int row, int nrad, int nang, int lane,
+                                           Loaded<NCH, BWD, GR>& ld) {
+  const float4* px = a.cl_xyz + (size_t)row * a.cl_stride;
+  const int* pj = a.cl_j + (size_t)row * a.cl_stride;
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
-    pf.xr[c] = px[kMaxAng + 64 * c + lane];
-    if constexpr (BWD) pf.jr[c] = pj[kMaxAng + 64 * c + lane];
+    const int t = 64 * c + lane;
+    ld.xx[c] = t < nrad ? px[slot_index(t, nang)] : make_float4(0.f, 0.f, 0.f, 1.f);
+    if constexpr (BWD) ld.jj[c] = t < nrad ? pj[slot_index(t, nang)] : 0;
   }
   if constexpr (BWD) {
     const int n4 = p.aev_stride >> 2;
-    const float4* g4 = reinterpret_cast<const float4*>(a.gaev + (size_t)rc * p.aev_stride);
+    const float4* g4 = reinterpret_cast<const float4*>(a.gaev + (size_t)row * p.aev_stride);
 #pragma unroll
-    for (int c = 0; c < GR; c++) pf.grow[c] = g4[min(lane + 64 * c, n4 - 1)];
+    for (int c = 0; c < GR; c++) ld.grow[c] = lane + 64 * c < n4 ? g4[lane + 64 * c] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-}
-template <int NCH, bool BWD, int GR>
-__device__ __forceinline__ void touch_prefetch(const Prefetched<NCH, BWD, GR>& pf) {
-  touch(pf.h0); touch(pf.h1); touch(pf.xa);
-  if constexpr (BWD) touch(pf.ja);
-#pragma unroll
-  for (int c = 0; c < NCH; c++) {
-    touch(pf.xr[c]);
-    if constexpr (BWD) touch(pf.jr[c]);
-  }
-  if constexpr (BWD) {
-#pragma unroll
-    for (int c = 0; c < GR; c++) touch(pf.grow[c]);
-  }
-}
-template <int NCH, bool BWD, int GR>
-__device__ __forceinline__ hdr_t scalar_header(const AevArgs& a, int row, const Prefetched<NCH, BWD, GR>& pf) {
-  hdr_t h;
-  h[0] = row < a.nrows ? __builtin_amdgcn_readfirstlane(pf.h0.x) : -1;
-  h[1] = __builtin_amdgcn_readfirstlane(pf.h0.y); h[2] = __builtin_amdgcn_readfirstlane(pf.h0.z);
-  h[3] = __builtin_amdgcn_readfirstlane(pf.h0.w); h[4] = __builtin_amdgcn_readfirstlane(pf.h1.x);
-  h[5] = __builtin_amdgcn_readfirstlane(pf.h1.y); h[6] = __builtin_amdgcn_readfirstlane(pf.h1.z);
-  h[7] = __builtin_amdgcn_readfirstlane(pf.h1.w);
-  return h;
 }
 __device__ __forceinline__ int hdr_nrad(const hdr_t& h) { return h[0] < 0 ? 0 : (h[1] & 0xffff); }
 __device__ __forceinline__ int hdr_nang(const hdr_t& h) { return h[0] < 0 ? 0 : ((h[1] >> 16) & 0xff); }
@@ -431,7 +415,7 @@ __device__ __forceinline__ void store_starts(const AevParams& p, const Groups& g
 // group starts in L.rstart / L.astart.  All per-species bookkeeping is scalar.
 template <int NCH>
 __device__ __forceinline__ void unpack_lists(const AevParams& p, const AevArgs& a, int row, const hdr_t& h,
-                                             const Prefetched<NCH, false, 1>& pf, int lane, FastLds& L, int& nrad, int& nang) {
+                                             const Loaded<NCH, false, 1>& ld, int lane, FastLds& L, int& nrad, int& nang) {
   nrad = hdr_nrad(h);
   nang = hdr_nang(h);
   const Groups g = unpack_groups(h);
@@ -439,40 +423,36 @@ __device__ __forceinline__ void unpack_lists(const AevParams& p, const AevArgs& 
   const float half_inv_Rcr = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;  // r/(2 Rcr) revolutions
   const float half_inv_Rca = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
   const float4* __restrict__ px = a.cl_xyz + (size_t)row * a.cl_stride;
-  // w-th entry of the angular (ang) or the radial-only stream -> position in the LDS radial list
-  auto place = [&](bool ang, int w, const float4& v) {
-    int pos = w;   // species 0: the radial-only entries follow its as[1] angular ones
-    int lead = g.as[1];
-#pragma unroll
-    for (int k = 1; k < 8; k++)
-      if (k < p.S) {
-        const int st = ang ? g.as[k] : g.r2[k];
-        if (w >= st) { pos = g.rs[k] + (w - st); lead = g.as[k + 1] - g.as[k]; }
-      }
-    if (!ang) pos += lead;
-    L.rr[pos] = v.w;
-    L.rfc[pos] = 0.5f * fcos_rev(v.w * half_inv_Rcr) + 0.5f;
-    if (ang) {
-      L.ad[w] = v;
-      L.afc[w] = 0.5f * fcos_rev(v.w * half_inv_Rca) + 0.5f;
-    }
-  };
-  for (int base = 0; base < nang; base += 64) {
-    const int t = base + lane;
-    if (t < nang) place(true, t, base == 0 ? pf.xa : px[t]);   // more than 64 angular neighbours: loaded in place
-  }
-  const int nr2 = nrad - nang;
-  for (int base = 0; base < nr2; base += 64) {
+  for (int base = 0; base < nrad; base += 64) {
     const int c = base >> 6, t = base + lane;
     float4 v = make_float4(0.f, 0.f, 0.f, 1.f);
     if (c < NCH) {
 #pragma unroll
       for (int k = 0; k < NCH; k++)
-        if (c == k) v = pf.xr[k];
-    } else if (t < nr2) {
-      v = px[kMaxAng + t];
+        if (c == k) v = ld.xx[k];
+    } else if (t < nrad) {   // lists longer than the chunks held in registers: loaded in place
+      v = px[slot_index(t, nang)];
     }
-    if (t < nr2) place(false, t, v);
+    if (t < nrad) {
+      // w-th entry of the angular (ang) or the radial-only stream -> position in the LDS radial list
+      const bool ang = t < nang;
+      const int w = ang ? t : t - nang;
+      int pos = w;   // species 0: the radial-only entries follow its as[1] angular ones
+      int lead = g.as[1];
+#pragma unroll
+      for (int k = 1; k < 8; k++)
+        if (k < p.S) {
+          const int st = ang ? g.as[k] : g.r2[k];
+          if (w >= st) { pos = g.rs[k] + (w - st); lead = g.as[k + 1] - g.as[k]; }
+        }
+      if (!ang) pos += lead;
+      L.rr[pos] = v.w;
+      L.rfc[pos] = 0.5f * fcos_rev(v.w * half_inv_Rcr) + 0.5f;
+      if (ang) {
+        L.ad[w] = v;
+        L.afc[w] = 0.5f * fcos_rev(v.w * half_inv_Rca) + 0.5f;
+      }
+    }
   }
 }
 
@@ -645,7 +625,7 @@ __device__ __forceinline__ void build_row_descriptors(FastLds& L, int nbk, int n
 
 template <int NA, int NZ, int NCH>
 __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
-                                               const Prefetched<NCH, false, 1>& pf, int lane) {
+                                               const Loaded<NCH, false, 1>& pf, int lane) {
   constexpr int NR = 16, Q = 64 / NA;
   for (int e = lane; e < (p.aev_stride >> 2); e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
   int nrad, nang;
@@ -798,11 +778,11 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
 #define ANI_PERSISTENT_LOOP(KW, NCH, BWD, GR, CENTRE)                                                      \
   const int nw = gridDim.x * KW;                                                                          \
   for (int row = blockIdx.x * KW + wave; row < a.nrows; row += nw) {                                      \
-    Prefetched<NCH, BWD, GR> cur;                                                                         \
-    issue_prefetch(p, a, row, lane, cur);                                                                 \
-    touch_prefetch(cur);                                                                                  \
-    const hdr_t hc = scalar_header(a, row, cur);                                                          \
-    if (hc[0] >= 0) { CENTRE; }                                                                           \
+    const hdr_t hc = load_header(a, row);                                                                 \
+    if (hc[0] < 0) continue;                                                                              \
+    Loaded<NCH, BWD, GR> cur;                                                                             \
+    load_lists(p, a, row, hdr_nrad(hc), hdr_nang(hc), lane, cur);                                         \
+    CENTRE;                                                                                               \
   }
 
 template <int NA, int NZ, int NCH>
@@ -829,7 +809,7 @@ __device__ __forceinline__ void scatter_neighbours(const AevArgs& a, const float
 
 template <int NA, int NZ, int NCH, int GR, bool VIR>
 __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
-                                                const Prefetched<NCH, true, GR>& pf, int lane, float (&wv)[9],
+                                                const Loaded<NCH, true, GR>& pf, int lane, float (&wv)[9],
                                                 const RepTab& rep, float& er) {
   constexpr int NR = 16;
   const int centre = h[0];
@@ -851,22 +831,20 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   const float revA = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
   const float4* __restrict__ px = a.cl_xyz + (size_t)row * a.cl_stride;
   const int* __restrict__ pj = a.cl_j + (size_t)row * a.cl_stride;
-  // chunks: the angular region first (ceil(nang / 64) of them), then the radial-only region
-  const int nr2 = nrad - nang, cha = (nang + 63) >> 6, chr = (nr2 + 63) >> 6;
-  for (int ch = 0; ch < cha + chr; ch++) {
-    const bool ang = ch < cha;
-    const int c = ang ? ch : ch - cha, w = 64 * c + lane;   // w: index in its stream
-    const bool live = w < (ang ? nang : nr2);
+  // chunks of the compact list in slot order: lanes with t < nang hold angular neighbours, the others radial-only ones
+  for (int base = 0; base < nrad; base += 64) {
+    const int c = base >> 6, t0 = base + lane;
+    const bool live = t0 < nrad, ang = t0 < nang;
+    const int w = ang ? t0 : t0 - nang;   // index in its stream
     float4 v = make_float4(0.f, 0.f, 0.f, 1.f);
     int j = 0;
-    if (ang && c == 0) { v = pf.xa; j = pf.ja; }
-    else if (!ang && c < NCH) {
+    if (c < NCH) {
 #pragma unroll
       for (int k = 0; k < NCH; k++)
-        if (c == k) { v = pf.xr[k]; j = pf.jr[k]; }
-    } else if (live) {  // lists longer than the prefetched chunks: loaded in place
-      v = px[(ang ? 0 : kMaxAng) + w];
-      j = pj[(ang ? 0 : kMaxAng) + w];
+        if (c == k) { v = pf.xx[k]; j = pf.jj[k]; }
+    } else if (live) {  // lists longer than the chunks held in registers: loaded in place
+      v = px[slot_index(t0, nang)];
+      j = pj[slot_index(t0, nang)];
     }
     const int t = w;   // angular neighbours: index of the LDS accumulators
     float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -929,9 +907,9 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     // radial-only neighbours: finished here (scattered at once; ONE merged scatter per centre -- angular + radial-only +
     // centre, 21 atoms per atomic instruction instead of 16 -- was measured: 5 % slower, the atomics then leave in one
     // burst at the end of the centre instead of two spread over it)
-    if (!ang) {   // wave-uniform
-      const int lo = 0, hi = min(nr2 - 64 * c, 64);
-      if (live) {
+    const int lo = min(max(nang - base, 0), 64), hi = min(nrad - base, 64);   // radial-only lanes of this chunk: [lo, hi)
+    if (hi > lo) {   // wave-uniform
+      if (live && !ang) {
         fx += gx; fy += gy; fz += gz;
         if constexpr (VIR) {
           wv[0] += gx * v.x; wv[1] += gx * v.y; wv[2] += gx * v.z;
