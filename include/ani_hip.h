@@ -169,6 +169,9 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *   "mlp_chain" (default 1): with one ensemble member and few row tiles (small systems) the six MLP products run as one
  *       chained launch instead of six grouped ones; 2 = at any size (measurement knob), 0 = never.  Takes effect at the
  *       next call.
+ *   "device_overwrite_forces" (default 0): ani_compute_full_device ADDS forces into d_f like the reference's Kokkos
+ *       overload (src/pair_ani_kokkos.cpp:190-191); 1 makes it overwrite d_f[0 .. 3*ntotal) instead, for callers that
+ *       would otherwise clear the array first.  Takes effect at the next call.
  *   "profiling" (default 0): the reference's LAMMPS_ANI_PROFILING (src/pair_ani.cpp:49-50, src/pair_ani_kokkos.cpp:68-70,
  *       210-212): ani_compute_full_device synchronises its stream before it returns, so the caller's host timers
  *       (LAMMPS' timing breakdown) charge the device work to the pair style.  The host-pointer entry points always

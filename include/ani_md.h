@@ -1,0 +1,41 @@
+/*
+ * ani_md.h — device kernels of the LAMMPS-free timestep loop (lammps-ani_amd/md.py, bench.py, tests).
+ *
+ * NOT part of the drop-in boundary (that is ani_hip.h).  Under LAMMPS these steps are LAMMPS' own: `fix nve`
+ * (initial_integrate / final_integrate), `fix langevin` (post_force), Neighbor::check_distance, and the forward / reverse
+ * ghost communication of Comm.  The stand-in loop that produces bench.py's MD rate runs them on the device; fused here so
+ * that a step is five small launches around the hot path instead of a dozen tensor operations.
+ * Units: LAMMPS `real` (A, fs, g/mol, kcal/mol).  Every pointer is device memory; `stream` is a hipStream_t (NULL: the
+ * default stream); nothing synchronises.  Return 0 on success, else a hipError_t value.
+ */
+#ifndef ANI_MD_H
+#define ANI_MD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* fix nve, initial_integrate:  v += dtfm[i] f ;  x += dt v  for the nlocal owned atoms (dtfm[i] = dt/2 * ftm2v / mass_i),
+ * and Neighbor::check_distance folded in:  *d2max = max(*d2max, |x_i - x_built_i|^2)  (the caller zeroes *d2max when it
+ * has read it).  x, v, f: [n][3]. */
+int ani_md_initial_integrate(double* x, double* v, const double* f, const double* dtfm, double dt, int nlocal,
+                             const double* x_built, double* d2max, void* stream);
+
+/* fix langevin (post_force) + fix nve final_integrate:  f += g1[i] v + g2[i] r  with r uniform in [-0.5, 0.5) per
+ * component (a counter-based generator keyed by seed, step and the atom's global tag: the same atom draws the same
+ * numbers whatever rank owns it), skipped when langevin == 0;  then  v += dtfm[i] f. */
+int ani_md_final_integrate(double* v, double* f, const double* dtfm, int nlocal, int langevin, const double* g1,
+                           const double* g2, const int64_t* tag, uint64_t seed, uint64_t step, void* stream);
+
+/* Comm::forward_comm on one rank (periodic self-images):  x[nlocal + g] = x[owner[g]] + shift[g] */
+int ani_md_forward_ghosts(double* x, const int64_t* owner, const double* shift, int nlocal, int nghost, void* stream);
+
+/* the pair style's reverse communication on one rank:  f[owner[g]] += f[nlocal + g] */
+int ani_md_reverse_ghosts(double* f, const int64_t* owner, int nlocal, int nghost, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANI_MD_H */

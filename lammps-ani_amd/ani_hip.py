@@ -84,6 +84,13 @@ def lib():
         L.ani_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.ani_debug_colmap.argtypes = [C.c_void_p, C.c_void_p]
         L.ani_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        # include/ani_md.h: kernels of the LAMMPS-free timestep loop (not part of the drop-in boundary)
+        L.ani_md_initial_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]
+        L.ani_md_final_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.ani_md_forward_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ani_md_reverse_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ani_phase_timing.argtypes = [C.c_void_p, C.c_int]
         L.ani_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _lib = L

@@ -90,6 +90,7 @@ struct ani_handle {
   int mlp_chain = 1;   // ani_set_option("mlp_chain"): 1 = one chained launch for the MLP of small systems, 2 = at any size, 0 = never
   ChainPlan chain_plan;
   bool profiling = false;  // ani_set_option("profiling"): every entry point synchronises its stream before returning
+  bool dev_overwrite = false;  // ani_set_option("device_overwrite_forces"): ani_compute_full_device writes d_f instead of adding
   bool mlp_split = true;  // ani_set_option("mlp_split_bf16"): six bf16 MFMA products per fp32 product instead of fp32-input MFMA
   std::vector<int> colmap;  // ap_run column -> ap column
   int device = 0;
@@ -874,7 +875,7 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
     if (rc) return rc;
     h->have_list = true;
   }
-  rc = run_step(h, d_x, eflag_atom, vflag, d_f, /*accumulate=*/1, d_ev, d_eatom, st);
+  rc = run_step(h, d_x, eflag_atom, vflag, d_f, /*accumulate=*/h->dev_overwrite ? 0 : 1, d_ev, d_eatom, st);
   // LAMMPS_ANI_PROFILING (src/pair_ani_kokkos.cpp:68-70,210-212): the host's timers see the device work of this call
   if (rc == ANI_OK && h->profiling) HIP_TRY(h, hipStreamSynchronize(st));
   return rc;
@@ -1096,6 +1097,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   }
   if (strcmp(name, "mlp_split_bf16") == 0) {
     h->mlp_split = value != 0;
+    return ANI_OK;
+  }
+  if (strcmp(name, "device_overwrite_forces") == 0) {
+    h->dev_overwrite = value != 0;
     return ANI_OK;
   }
   if (strcmp(name, "profiling") == 0) {

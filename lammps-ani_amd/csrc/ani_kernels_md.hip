@@ -1,0 +1,113 @@
+// ani_kernels_md.hip — the timestep loop's own kernels (include/ani_md.h): what LAMMPS' fix nve, fix langevin,
+// Neighbor::check_distance and Comm do around PairANI::compute in the reference's runs
+// (examples/benchmark/in.lammps:24-27,54-72).  Test / bench infrastructure of the LAMMPS-free loop, not the pair style.
+#include <hip/hip_runtime.h>
+
+#include "../../include/ani_md.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void initial_integrate_kernel(double* __restrict__ x, double* __restrict__ v,
+                                                                const double* __restrict__ f, const double* __restrict__ dtfm,
+                                                                double dt, int n, const double* __restrict__ xb,
+                                                                double* __restrict__ d2max) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double d2 = 0.0;
+  if (i < n) {
+    const double s = dtfm[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double vk = v[3 * i + k] + s * f[3 * i + k];
+      const double xk = x[3 * i + k] + dt * vk;
+      v[3 * i + k] = vk;
+      x[3 * i + k] = xk;
+      const double d = xk - xb[3 * i + k];
+      d2 += d * d;
+    }
+  }
+  // wave maximum, then one atomic per wave; non-negative doubles order like their bit patterns
+  for (int off = 32; off > 0; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off));
+  if ((threadIdx.x & 63) == 0 && d2 > 0.0)
+    atomicMax(reinterpret_cast<unsigned long long*>(d2max), (unsigned long long)__double_as_longlong(d2));
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {   // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void final_integrate_kernel(double* __restrict__ v, double* __restrict__ f,
+                                                              const double* __restrict__ dtfm, int n, int langevin,
+                                                              const double* __restrict__ g1, const double* __restrict__ g2,
+                                                              const long long* __restrict__ tag, unsigned long long seed,
+                                                              unsigned long long step) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double s = dtfm[i];
+  const unsigned long long key = mix64(seed + 0x9E3779B97F4A7C15ULL * (step + 1)) ^ (0xD1B54A32D192ED03ULL * (unsigned long long)(tag ? tag[i] : i));
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    double fk = f[3 * i + k];
+    const double vk = v[3 * i + k];
+    if (langevin) {
+      const unsigned long long h = mix64(key + 0x9E3779B97F4A7C15ULL * (k + 1));
+      const double r = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;   // uniform in [-0.5, 0.5)
+      fk += g1[i] * vk + g2[i] * r;
+      f[3 * i + k] = fk;
+    }
+    v[3 * i + k] = vk + s * fk;
+  }
+}
+
+__global__ __launch_bounds__(256) void forward_ghosts_kernel(double* __restrict__ x, const long long* __restrict__ owner,
+                                                             const double* __restrict__ shift, int nlocal, int nghost) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * nghost) return;
+  const int g = t / 3, k = t - 3 * g;
+  x[3 * (size_t)nlocal + t] = x[3 * owner[g] + k] + shift[t];
+}
+
+__global__ __launch_bounds__(256) void reverse_ghosts_kernel(double* __restrict__ f, const long long* __restrict__ owner,
+                                                             int nlocal, int nghost) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * nghost) return;
+  const int g = t / 3, k = t - 3 * g;
+  atomicAdd(&f[3 * owner[g] + k], f[3 * (size_t)nlocal + t]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ani_md_initial_integrate(double* x, double* v, const double* f, const double* dtfm, double dt, int nlocal,
+                             const double* x_built, double* d2max, void* stream) {
+  if (nlocal <= 0) return 0;
+  hipLaunchKernelGGL(initial_integrate_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, v, f, dtfm, dt,
+                     nlocal, x_built, d2max);
+  return (int)hipGetLastError();
+}
+
+int ani_md_final_integrate(double* v, double* f, const double* dtfm, int nlocal, int langevin, const double* g1,
+                           const double* g2, const int64_t* tag, uint64_t seed, uint64_t step, void* stream) {
+  if (nlocal <= 0) return 0;
+  hipLaunchKernelGGL(final_integrate_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, f, dtfm, nlocal,
+                     langevin, g1, g2, reinterpret_cast<const long long*>(tag), (unsigned long long)seed, (unsigned long long)step);
+  return (int)hipGetLastError();
+}
+
+int ani_md_forward_ghosts(double* x, const int64_t* owner, const double* shift, int nlocal, int nghost, void* stream) {
+  if (nghost <= 0) return 0;
+  hipLaunchKernelGGL(forward_ghosts_kernel, dim3((3 * nghost + 255) / 256), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<const long long*>(owner), shift, nlocal, nghost);
+  return (int)hipGetLastError();
+}
+
+int ani_md_reverse_ghosts(double* f, const int64_t* owner, int nlocal, int nghost, void* stream) {
+  if (nghost <= 0) return 0;
+  hipLaunchKernelGGL(reverse_ghosts_kernel, dim3((3 * nghost + 255) / 256), dim3(256), 0, (hipStream_t)stream, f,
+                     reinterpret_cast<const long long*>(owner), nlocal, nghost);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

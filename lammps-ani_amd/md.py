@@ -65,8 +65,18 @@ class VerletRun:
         self.nbuilds = 0
         self.npairs = 0
         self._stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else None
+        # on the GPU the loop's own steps (fix nve, fix langevin, displacement check, one-rank ghost copies) are the fused
+        # kernels of include/ani_md.h; the tensor-operation forms below remain for reading and for other devices
+        self._fused = torch.device(device).type == "cuda"
+        self._seed = int(seed)
+        if self._fused:
+            from . import ani_hip
+            self._md = ani_hip.lib()
+            self._d2max = torch.zeros(1, dtype=torch.float64, device=device)
+            ani.set_option("device_overwrite_forces", 1)   # no separate force_clear launch
         self._build_list()
         self._forces()
+        self._post_force()
 
     # ---- pieces of the loop ---------------------------------------------------------------------------
     def _allreduce_max(self, t: torch.Tensor) -> float:
@@ -84,13 +94,16 @@ class VerletRun:
         n = self.nlocal
         m = self.masses[self.species[:n].long()]
         self.mass = m[:, None]
-        self._dtf_over_m = ((0.5 * self.dt * FTM2V) / self.mass).expand(-1, 3).contiguous()
+        self._dtfm1 = ((0.5 * self.dt * FTM2V) / m).contiguous()          # [n], the fused kernels' form
+        self._dtf_over_m = self._dtfm1[:, None].expand(-1, 3).contiguous()
         self._lang = None
+        self._g1 = self._g2 = None
         if self.langevin is not None:
             T, damp = self.langevin
-            g1 = (-self.mass / damp / FTM2V).expand(-1, 3).contiguous()
-            g2 = (torch.sqrt(self.mass) * (24.0 * BOLTZ * T / damp / self.dt / MVV2E) ** 0.5 / FTM2V).expand(-1, 3).contiguous()
-            self._lang = (g1, g2, torch.empty((n, 3), dtype=torch.float64, device=self.device))
+            self._g1 = (-m / damp / FTM2V).contiguous()
+            self._g2 = (torch.sqrt(m) * (24.0 * BOLTZ * T / damp / self.dt / MVV2E) ** 0.5 / FTM2V).contiguous()
+            self._lang = (self._g1[:, None].expand(-1, 3).contiguous(), self._g2[:, None].expand(-1, 3).contiguous(),
+                          torch.empty((n, 3), dtype=torch.float64, device=self.device))
 
     def _build_list(self):
         """Domain::pbc + Comm::exchange + Comm::borders + Neighbor::build."""
@@ -108,16 +121,31 @@ class VerletRun:
         self.npairs = self.ani.build_list_device(self.ntotal, n, self.species.data_ptr(), self.x.data_ptr(),
                                                  self.cutneigh, lo, hi, stream=self._stream)
         self.x_built = self.x[:n].clone()
+        if self._fused:
+            self._d2max.zero_()
         self.since_build = 0
         self.nbuilds += 1
 
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"ani_md kernel launch failed (hipError {rc})")
+
     def _forces(self):
-        self.f.zero_()
+        """force_clear + PairANI::compute + reverse communication of the ghost forces"""
+        if not self._fused:
+            self.f.zero_()
         self.ani.compute_device(self.ntotal, self.nlocal, None, self.x.data_ptr(), self.npairs, None, None, None, 1,
                                 self.f.data_ptr(), self.ev.data_ptr(), stream=self._stream)
-        self.dc.reverse_add(self.f)
+        if self._fused and self.dc.world == 1:
+            self._check(self._md.ani_md_reverse_ghosts(self.f.data_ptr(), self.dc.send_idx.data_ptr(), self.nlocal,
+                                                       self.ntotal - self.nlocal, self._stream))
+        else:
+            self.dc.reverse_add(self.f)
+
+    def _post_force(self):
+        """fix langevin (LAMMPS fix_langevin.cpp, uniform random numbers in [-0.5, 0.5)): f += g1 v + g2 r on owned atoms.
+        Tensor-operation form: set-up, and devices without the fused kernels (step() fuses it with final_integrate)."""
         if self._lang is not None:
-            # fix langevin (LAMMPS fix_langevin.cpp, uniform random numbers in [-0.5, 0.5)): f += g1 v + g2 r on owned atoms
             g1, g2, r = self._lang
             r.uniform_(-0.5, 0.5, generator=self.gen)
             fl = self.f[: self.nlocal]
@@ -155,16 +183,25 @@ class VerletRun:
         return float(t)
 
     def step(self):
-        # fix nve initial_integrate: v += dtf f / m ; x += dt v
-        self.v.addcmul_(self.f[: self.nlocal], self._dtf_over_m)
-        self.x[: self.nlocal].add_(self.v, alpha=self.dt)
+        # fix nve initial_integrate: v += dtf f / m ; x += dt v  (fused: + the displacement maximum of check_distance)
+        if self._fused:
+            self._check(self._md.ani_md_initial_integrate(self.x.data_ptr(), self.v.data_ptr(), self.f.data_ptr(),
+                                                          self._dtfm1.data_ptr(), self.dt, self.nlocal, self.x_built.data_ptr(),
+                                                          self._d2max.data_ptr(), self._stream))
+        else:
+            self.v.addcmul_(self.f[: self.nlocal], self._dtf_over_m)
+            self.x[: self.nlocal].add_(self.v, alpha=self.dt)
         self.step_no += 1
         self.since_build += 1
         # Neighbor::decide + check_distance (every N steps, rebuild if any atom moved more than skin/2)
         rebuild = False
         if self.since_build % self.every == 0:
-            d2 = (self.x[: self.nlocal] - self.x_built).square().sum(1).max().reshape(1) if self.nlocal else \
-                torch.zeros(1, dtype=torch.float64, device=self.device)
+            if self._fused:
+                d2 = self._d2max.clone()    # running maximum since the last look (monotone between rebuilds: same decision)
+                self._d2max.zero_()
+            else:
+                d2 = (self.x[: self.nlocal] - self.x_built).square().sum(1).max().reshape(1) if self.nlocal else \
+                    torch.zeros(1, dtype=torch.float64, device=self.device)
             # the same host round trip carries the health of the last force evaluation: the device entry point cannot
             # return ANI_ERR_CAPACITY (nothing synchronises), it turns the energy into NaN instead
             d2 = torch.where(torch.isfinite(self.ev[:1]), d2, torch.full_like(d2, float("inf")))
@@ -175,11 +212,22 @@ class VerletRun:
             rebuild = worst > (0.5 * self.skin) ** 2
         if rebuild:
             self._build_list()
+        elif self._fused and self.dc.world == 1:
+            self._check(self._md.ani_md_forward_ghosts(self.x.data_ptr(), self.dc.send_idx.data_ptr(), self.dc.send_shift.data_ptr(),
+                                                       self.nlocal, self.ntotal - self.nlocal, self._stream))
         else:
             self.dc.forward_positions(self.x)
         self._forces()
-        # fix nve final_integrate
-        self.v.addcmul_(self.f[: self.nlocal], self._dtf_over_m)
+        # fix langevin post_force + fix nve final_integrate
+        if self._fused:
+            lang = self._g1 is not None
+            self._check(self._md.ani_md_final_integrate(self.v.data_ptr(), self.f.data_ptr(), self._dtfm1.data_ptr(), self.nlocal,
+                                                        1 if lang else 0, self._g1.data_ptr() if lang else None,
+                                                        self._g2.data_ptr() if lang else None, self.tag.data_ptr(), self._seed,
+                                                        self.step_no, self._stream))
+        else:
+            self._post_force()
+            self.v.addcmul_(self.f[: self.nlocal], self._dtf_over_m)
 
     # ---- thermo ------------------------------------------------------------------------------------------
     def kinetic_energy(self) -> float:

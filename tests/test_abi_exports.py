@@ -19,6 +19,23 @@ def test_every_declared_symbol_is_exported():
     assert set(ani_hip.EXPORTS) == set(declared)
 
 
+def test_every_header_under_include_is_exported():
+    """include/ani_md.h (the timestep loop's own kernels: not the drop-in boundary, but a C ABI of the same library)."""
+    from lammps_ani_amd import ani_hip
+    ani_hip.build()
+    lib = C.CDLL(ani_hip.LIB_PATH)
+    inc = os.path.join(ROOT, "include")
+    seen = 0
+    for name in sorted(os.listdir(inc)):
+        if not name.endswith(".h"):
+            continue
+        hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, name)).read(), flags=re.S)
+        for sym in sorted(set(re.findall(r"\b(ani_[a-z_0-9]+)\s*\(", hdr))):
+            assert hasattr(lib, sym), f"{sym} declared in include/{name} but not exported"
+            seen += 1
+    assert seen >= 28
+
+
 def test_create_fails_loudly_without_gpu_or_for_cpu_device(tmp_path):
     """No GPU in the build container: ani_create must return an error, never fall back."""
     import torch

@@ -3,7 +3,7 @@
 # usage: tools/abl_build.sh NAME "-DABL_X -DABL_Y" [NAME2 "flags2" ...]
 set -e
 cd "$(dirname "$0")/../lammps-ani_amd/csrc"
-OBJS="ani_hip.o ani_model.o ani_kernels_mlp.o ani_kernels_misc.o ani_kernels_f64.o ani_kernels_nbr.o ani_kernels_rep.o"
+OBJS="ani_hip.o ani_model.o ani_kernels_mlp.o ani_kernels_misc.o ani_kernels_f64.o ani_kernels_nbr.o ani_kernels_rep.o ani_kernels_md.o"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   ( hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result $flags -c ani_kernels_aev.hip -o ../../tools/abl/aev_$name.o &&
