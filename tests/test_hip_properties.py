@@ -305,3 +305,25 @@ def test_radial_capacity_overflow_is_retried_with_full_capacity(model_cache, hip
     assert "full_radial_capacity" not in capfd.readouterr().err
     assert np.abs(got2["force"] - got["force"]).max() < 1e-3
     ani.close()
+
+
+def test_local_rank_maps_onto_the_visible_devices(model_cache, hip):
+    """src/pair_ani.cpp:255-283: the node-local MPI rank is taken modulo the number of visible devices.  On a one-GPU box
+    every rank lands on device 0 and computes the same thing; -1 (the reference's `device cpu`) is refused."""
+    import torch
+    p = model_cache("ani2x", 1, 2024)
+    inp = hx.decompose(hx.water_box(300, seed=5))
+    ndev = torch.cuda.device_count()
+    ref = None
+    for local_rank in (0, 1, 5, 8 * ndev + 3):
+        ani = hip.ANI(p, local_rank)
+        out = ani.compute(inp, ago=0)
+        if local_rank % ndev == 0:
+            if ref is None:
+                ref = out
+            assert np.array_equal(out["force"], ref["force"]) and out["energy"] == ref["energy"]   # same device, same bits
+        else:
+            assert np.abs(out["force"] - ref["force"]).max() < F_TOL
+        ani.close()
+    with pytest.raises(hip.AniError, match="cpu"):
+        hip.ANI(p, -1)
