@@ -345,12 +345,13 @@ def main():
                         kernel="gemm_grouped_x3 (MLP forward + backward: 6 grouped launches per step, all species and members)",
                         ms_per_step=t_mlp, flops_per_step=flops, flops_per_step_full_width_aev=flops_dense, aev_columns=aev_cols,
                         note="achieved = algorithmic fp32 flops / time, peak = the fp32-input MFMA peak.  The kernel evaluates each "
-                             "fp32 product as six v_mfma_f32_32x32x16_bf16 products of the exact hi/mid/lo bf16 splits of both "
-                             "operands (fp32 accumulate; same force error against the fp64 oracle as the fp32-input MFMA path, "
-                             "option mlp_split_bf16=0), so the MFMA pipe executes 6x these flops at the bf16 rate")
+                             "fp32 product as three v_mfma_f32_32x32x16_f16 products of two-term fp16 splits of the power-of-two "
+                             "scaled operands (operands to 2^-22, fp32 accumulate; `parity` below holds the force error against "
+                             "the fp64 oracle for this path, for the exact six-product bf16 split (option mlp_arith=1) and for "
+                             "the fp32-input MFMA instruction (mlp_arith=0)), so the MFMA pipe executes 3x these flops at the fp16 rate")
         mlp_roof["frac"] = mlp_roof["achieved"] / PEAK_F32_MFMA_TFLOPS if mlp_roof["achieved"] else None
-        # share of the step's MLP time the MFMA pipes are busy: 6 bf16 instructions of 32 cycles per 32x32x16 block
-        mlp_roof["mfma_pipe_busy_frac"] = (flops * 6 / (2 * 32 * 32 * 16) * 32 / (1024 * 2.4e9)) / (t_mlp * 1e-3) if t_mlp > 0 else None
+        # share of the step's MLP time the MFMA pipes are busy: 3 fp16 instructions of 32 cycles per 32x32x16 block
+        mlp_roof["mfma_pipe_busy_frac"] = (flops * 3 / (2 * 32 * 32 * 16) * 32 / (1024 * 2.4e9)) / (t_mlp * 1e-3) if t_mlp > 0 else None
 
         what = "static positions, list reused (hot path only)" if args.no_md else \
             "velocity Verlet + Langevin 300 K, dt 0.5 fs, skin 2.0, rebuild check every 10 steps, all on the device"
@@ -401,16 +402,20 @@ def main():
                              "max_abs_force": float(np.abs(fr).max()), "rms_force": float(np.sqrt((fr ** 2).mean())),
                              "energy_err_kcal_mol": float(abs(energy_local - ref["energy"])),
                              "tolerance_note": "north_star bar: 1e-4 eV/A = 2.3e-3 kcal/mol/A"}
-            # the same step with the MLP on fp32-input MFMA (v_mfma_f32_32x32x2_f32) instead of the split-bf16 products
-            ani.set_option("mlp_split_bf16", 0)
-            dt32, ph32 = wl.timed_run(max(args.steps // 5, 1), 2)
-            f32 = wl.d_f.view(-1, 3).cpu().numpy()
-            e32 = np.abs(f32[: inp.nlocal] - fr)
-            out["parity"]["fp32_input_mfma_path"] = {
-                "max_abs_force_err_kcal_mol_A": float(e32.max()), "rms_force_err": float(np.sqrt((e32 ** 2).mean())),
-                "max_abs_force_diff_to_split_path": float(np.abs(f32[: inp.nlocal] - f[: inp.nlocal]).max()),
-                "mlp_ms_per_step": ph32["mlp"] / max(ph32["calls"], 1)}
-            ani.set_option("mlp_split_bf16", 1)
+            # the same step with the other two arithmetics of the MLP: the exact three-term bf16 split (six products) and the
+            # fp32-input MFMA instruction (v_mfma_f32_32x32x2_f32)
+            out["parity"]["mlp_arith"] = "2: three fp16 MFMA products of two-term splits (default)"
+            for key, arith in (("bf16x3_exact_split_path", 1), ("fp32_input_mfma_path", 0)):
+                ani.set_option("mlp_arith", arith)
+                dt32, ph32 = wl.timed_run(max(args.steps // 5, 1), 2)
+                f32 = wl.d_f.view(-1, 3).cpu().numpy()
+                e32 = np.abs(f32[: inp.nlocal] - fr)
+                out["parity"][key] = {
+                    "max_abs_force_err_kcal_mol_A": float(e32.max()), "p999_abs_force_err": float(np.percentile(e32, 99.9)),
+                    "rms_force_err": float(np.sqrt((e32 ** 2).mean())),
+                    "max_abs_force_diff_to_default_path": float(np.abs(f32[: inp.nlocal] - f[: inp.nlocal]).max()),
+                    "mlp_ms_per_step": ph32["mlp"] / max(ph32["calls"], 1)}
+            ani.set_option("mlp_arith", 2)
     wl.close()
 
     if rank == 0 and world == 1 and not args.no_extra and (args.atoms, args.models) == (100002, 1):

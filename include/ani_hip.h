@@ -162,10 +162,19 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *       nor as neighbour) are identically zero; with 1 the kernels work on the remaining columns only (ANI-2x water:
  *       128 of 1008) and the first-layer products use the matching weight columns — the same sums without the zero
  *       terms.  0 forces the full 1008-column layout.
- *   "mlp_split_bf16" (default 1): the MLP evaluates every fp32 product as six v_mfma_f32_32x32x16_bf16 products of the
- *       exact hi/mid/lo bf16 splits of both operands, accumulated in fp32 (error of the dropped terms < 2^-23 relative,
- *       one fp32 rounding; 2.7x the matrix rate of the fp32-input instruction).  0 uses v_mfma_f32_32x32x2_f32.
- *       Takes effect at the next call.
+ *   "mlp_arith" (default 2): how the MLP evaluates its fp32 products; fp32 accumulation in every case, takes effect at
+ *       the next call.
+ *         2 = three v_mfma_f32_32x32x16_f16 products of two-term fp16 splits: every operand, scaled by a power of two
+ *             (weights so that a layer's largest sits below 2^13, activations by 2^4, gradients by 2^12; undone exactly on
+ *             the accumulators), is h + l with two fp16 numbers rounded to nearest -- good to 2^-22 relative (fp32: 2^-24)
+ *             for magnitudes within 2^16 of the tensor's range, 2^-25 / scale absolute below -- and the dropped l*l term is
+ *             below 2^-22 of the product.  Against the fp64 oracle the forces are as close as with 1 or 0 (the error
+ *             of the step is the AEV's fp32 arithmetic; bench.py "parity", tests/test_hip_properties.py).  An activation
+ *             beyond 4094 or a gradient beyond 16 Hartree per unit overflows fp16: inf, NaN energy, reported -- not wrong.
+ *         1 = six v_mfma_f32_32x32x16_bf16 products of the EXACT three-term bf16 splits (8+8+8 mantissa bits) of both
+ *             operands; the three dropped terms are below 2^-23 of the product: one fp32 rounding.  1.26x the MLP time of 2.
+ *         0 = the fp32-input instruction v_mfma_f32_32x32x2_f32 (1/16 of the 16-bit matrix rate on gfx950).
+ *   "mlp_split_bf16": earlier name; 1 selects "mlp_arith" 1, 0 selects "mlp_arith" 0.
  *   "mlp_chain" (default 1): with one ensemble member and few row tiles (small systems) the six MLP products run as one
  *       chained launch instead of six grouped ones; 2 = at any size (measurement knob), 0 = never.  Takes effect at the
  *       next call.

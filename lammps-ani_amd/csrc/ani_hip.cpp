@@ -73,10 +73,15 @@ struct SpeciesNet {
   // double-precision mirrors of the above (precision 'double' only)
   std::vector<double*> W64, b64, WT64;
   double *W0c64 = nullptr, *WT0c64 = nullptr, *w_out64 = nullptr, *b_out64 = nullptr;
-  // three-way bf16 splits of W / WT / W0c / WT0c for the split-bf16 MFMA path (blocked [N][ceil(K/16)][3][16])
-  std::vector<unsigned short*> W3, WT3;
-  unsigned short *W0c3 = nullptr, *WT0c3 = nullptr;
+  // 16-bit planes of W / WT / W0c / WT0c for the split MFMA paths (blocked [ceil(K/16)][N][planes][16]):
+  // sp[0] three bf16 planes (MLP_BF16X3), sp[1] two fp16 planes of wscale[k] * W (MLP_F16X2)
+  struct Planes {
+    std::vector<unsigned short*> W, WT;
+    unsigned short *W0c = nullptr, *WT0c = nullptr;
+  } sp[2];
+  std::vector<float> wscale;   // [L-1] power of two that brings the largest |weight| of layer k (all members) below 2^13
 };
+inline MlpArith planes_arith(int i) { return i == 0 ? MLP_BF16X3 : MLP_F16X2; }
 
 }  // namespace
 
@@ -91,7 +96,7 @@ struct ani_handle {
   ChainPlan chain_plan;
   bool profiling = false;  // ani_set_option("profiling"): every entry point synchronises its stream before returning
   bool dev_overwrite = false;  // ani_set_option("device_overwrite_forces"): ani_compute_full_device writes d_f instead of adding
-  bool mlp_split = true;  // ani_set_option("mlp_split_bf16"): six bf16 MFMA products per fp32 product instead of fp32-input MFMA
+  MlpArith mlp_arith = MLP_F16X2;  // ani_set_option("mlp_arith"): how the MLP evaluates its fp32 products (ani_kernels.h)
   std::vector<int> colmap;  // ap_run column -> ap column
   int device = 0;
   bool use_cuaev = true, use_fullnbr = true, use_single = true;
@@ -164,11 +169,16 @@ int mirror64(ani_handle* h, double** dst, const float* src, size_t n) {
   return ANI_OK;
 }
 
-// device copy of `batch` matrices [N][ld] (first K columns) as blocked bf16 hi/mid/lo planes
-int make_split(ani_handle* h, unsigned short** dst, const float* src, int batch, long long s_src, int N, int K, int ld) {
-  const size_t elems = split_bf16x3_elems(N, K) * (size_t)batch;
-  HIP_TRY(h, hipMalloc((void**)dst, std::max<size_t>(elems, 1) * sizeof(unsigned short)));
-  launch_split_bf16x3(src, batch, s_src, N, K, ld, *dst, nullptr);
+// device copies of `batch` matrices [N][ld] (first K columns) as blocked 16-bit planes, one per split arithmetic
+int make_split(ani_handle* h, unsigned short** dst3, unsigned short** dst2, const float* src, int batch, long long s_src, int N, int K,
+               int ld, float wscale) {
+  unsigned short** dst[2] = {dst3, dst2};
+  for (int i = 0; i < 2; i++) {
+    const MlpArith ar = planes_arith(i);
+    const size_t elems = split_elems(N, K, ar) * (size_t)batch;
+    HIP_TRY(h, hipMalloc((void**)dst[i], std::max<size_t>(elems, 1) * sizeof(unsigned short)));
+    launch_split_planes(src, batch, s_src, N, K, ld, ar, wscale, *dst[i], nullptr);
+  }
   HIP_TRY(h, hipDeviceSynchronize());
   return ANI_OK;
 }
@@ -187,9 +197,17 @@ int upload_model(ani_handle* h) {
     if (d[L - 1] > 256) { h->err = "last hidden layer wider than 256 is not supported"; return ANI_ERR_MODEL; }
     n.W.assign(L - 1, nullptr); n.b.assign(L - 1, nullptr); n.WT.assign(L - 1, nullptr);
     n.W64.assign(L - 1, nullptr); n.b64.assign(L - 1, nullptr); n.WT64.assign(L - 1, nullptr);
-    n.W3.assign(L - 1, nullptr); n.WT3.assign(L - 1, nullptr);
+    for (auto& sp : n.sp) { sp.W.assign(L - 1, nullptr); sp.WT.assign(L - 1, nullptr); }
+    n.wscale.assign(L - 1, 1.f);
     for (int k = 0; k < L - 1; k++) {
       const int out = d[k + 1], in = d[k], kp = n.w[k];
+      float wmax = 0.f;
+      for (int a = 0; a < M; a++)
+        for (float v : m.W[a][s][k]) wmax = std::max(wmax, std::fabs(v));
+      if (!std::isfinite(wmax)) { h->err = "non-finite weight in the model file"; return ANI_ERR_MODEL; }
+      int e = 0;
+      if (wmax > 0.f) (void)std::frexp(wmax, &e);   // wmax = f * 2^e, f in [0.5, 1)
+      n.wscale[k] = std::ldexp(1.f, std::max(-24, std::min(24, 13 - e)));
       std::vector<float> W((size_t)M * out * kp, 0.f), b((size_t)M * out);
       for (int a = 0; a < M; a++) {
         for (int o = 0; o < out; o++) {
@@ -201,7 +219,7 @@ int upload_model(ani_handle* h) {
       rc = upload(h, &n.b[k], b); if (rc) return rc;
       rc = mirror64(h, &n.W64[k], n.W[k], W.size()); if (rc) return rc;
       rc = mirror64(h, &n.b64[k], n.b[k], b.size()); if (rc) return rc;
-      rc = make_split(h, &n.W3[k], n.W[k], M, (long long)out * kp, out, kp, kp); if (rc) return rc;
+      rc = make_split(h, &n.sp[0].W[k], &n.sp[1].W[k], n.W[k], M, (long long)out * kp, out, kp, kp, n.wscale[k]); if (rc) return rc;
       // transposed copies for the backward products
       if (k == 0) {
         const int w1 = n.w[1];
@@ -211,7 +229,7 @@ int upload_model(ani_handle* h) {
             for (int i = 0; i < in; i++) T[(size_t)i * M * w1 + (size_t)a * w1 + o] = m.W[a][s][0][(size_t)o * in + i];
         rc = upload(h, &n.WT[0], T); if (rc) return rc;
         rc = mirror64(h, &n.WT64[0], n.WT[0], T.size()); if (rc) return rc;
-        rc = make_split(h, &n.WT3[0], n.WT[0], 1, 0, m.aev_len, M * w1, M * w1); if (rc) return rc;
+        rc = make_split(h, &n.sp[0].WT[0], &n.sp[1].WT[0], n.WT[0], 1, 0, m.aev_len, M * w1, M * w1, n.wscale[0]); if (rc) return rc;
       } else {
         const int wk1 = n.w[k + 1 < L ? k + 1 : k];  // K of the backward product through layer k = padded d[k+1]
         std::vector<float> T((size_t)M * in * wk1, 0.f);         // [M][d[k]][w(k+1)]
@@ -220,7 +238,7 @@ int upload_model(ani_handle* h) {
             for (int i = 0; i < in; i++) T[((size_t)a * in + i) * wk1 + o] = m.W[a][s][k][(size_t)o * in + i];
         rc = upload(h, &n.WT[k], T); if (rc) return rc;
         rc = mirror64(h, &n.WT64[k], n.WT[k], T.size()); if (rc) return rc;
-        rc = make_split(h, &n.WT3[k], n.WT[k], M, (long long)in * wk1, in, wk1, wk1); if (rc) return rc;
+        rc = make_split(h, &n.sp[0].WT[k], &n.sp[1].WT[k], n.WT[k], M, (long long)in * wk1, in, wk1, wk1, n.wscale[k]); if (rc) return rc;
       }
     }
     {  // output layer
@@ -278,11 +296,13 @@ int specialize(ani_handle* h, int mask) {
     if (n.WT0c) (void)hipFree(n.WT0c);
     if (n.W0c64) (void)hipFree(n.W0c64);
     if (n.WT0c64) (void)hipFree(n.WT0c64);
-    if (n.W0c3) (void)hipFree(n.W0c3);
-    if (n.WT0c3) (void)hipFree(n.WT0c3);
+    for (auto& sp : n.sp) {
+      if (sp.W0c) (void)hipFree(sp.W0c);
+      if (sp.WT0c) (void)hipFree(sp.WT0c);
+      sp.W0c = sp.WT0c = nullptr;
+    }
     n.W0c = n.WT0c = nullptr;
     n.W0c64 = n.WT0c64 = nullptr;
-    n.W0c3 = n.WT0c3 = nullptr;
   }
   std::vector<int> act;
   for (int s = 0; s < m.S; s++) {
@@ -332,8 +352,8 @@ int specialize(ani_handle* h, int mask) {
     rc = upload(h, &n.WT0c, T); if (rc) return rc;
     rc = mirror64(h, &n.W0c64, n.W0c, W.size()); if (rc) return rc;
     rc = mirror64(h, &n.WT0c64, n.WT0c, T.size()); if (rc) return rc;
-    rc = make_split(h, &n.W0c3, n.W0c, M, (long long)out * astride, out, astride, astride); if (rc) return rc;
-    rc = make_split(h, &n.WT0c3, n.WT0c, 1, 0, alen, M * w1, M * w1); if (rc) return rc;
+    rc = make_split(h, &n.sp[0].W0c, &n.sp[1].W0c, n.W0c, M, (long long)out * astride, out, astride, astride, n.wscale[0]); if (rc) return rc;
+    rc = make_split(h, &n.sp[0].WT0c, &n.sp[1].WT0c, n.WT0c, 1, 0, alen, M * w1, M * w1, n.wscale[0]); if (rc) return rc;
   }
   return ANI_OK;
 }
@@ -444,6 +464,16 @@ int compute_mlp(ani_handle* h, hipStream_t st) {
   // every layer's problems and epilogue, in launch order: either six grouped launches or one chained launch
   std::vector<std::vector<GemmArgs>> layer_probs;
   std::vector<int> layer_epi;
+  const MlpArith arith = h->mlp_arith;
+  const int spi = arith == MLP_F16X2 ? 1 : 0;
+  // two-term fp16 path: power-of-two scales of the A operands (ani_kernels_mlp.hip): activations 2^4, gradients 2^12
+  const float a_fwd = arith == MLP_F16X2 ? 16.f : 1.f, a_bwd = arith == MLP_F16X2 ? 4096.f : 1.f;
+  auto set_planes = [&](GemmArgs& g, const unsigned short* planes, long long per_batch_matrices, float a_scale, float wscale) {
+    g.Btp = planes; g.kbp = (g.K + 15) / 16;
+    g.sBp = per_batch_matrices ? (long long)split_elems(g.N, g.K, arith) : 0;
+    g.a_scale = a_scale;
+    g.inv_scale = arith == MLP_F16X2 ? 1.f / (a_scale * wscale) : 1.f;
+  };
   auto base_args = [&](int s) {
     GemmArgs g{};
     g.rows = round_up(h->count[s], kRowTile);
@@ -467,14 +497,12 @@ int compute_mlp(ani_handle* h, hipStream_t st) {
         const int ka = h->ap_run.aev_stride;  // first layer over the AEV columns of the species present
         g.A = h->aev.p + (size_t)h->row_start[s] * ka; g.lda = ka; g.sA = 0;
         g.K = ka; g.Bt = n.W0c ? n.W0c : n.W[0]; g.ldb = ka; g.sB = (long long)d[1] * ka;
-        g.Bt3 = n.W0c ? n.W0c3 : n.W3[0];
       } else {
         g.A = h->Hbuf[s][k]; g.lda = M * n.w[k]; g.sA = n.w[k];
         g.K = n.w[k]; g.Bt = n.W[k]; g.ldb = n.w[k]; g.sB = (long long)d[k + 1] * n.w[k];
-        g.Bt3 = n.W3[k];
       }
       g.N = d[k + 1];
-      g.kb3 = (g.K + 15) / 16; g.sB3 = (long long)split_bf16x3_elems(g.N, g.K);
+      set_planes(g, (k == 0 && n.W0c) ? n.sp[spi].W0c : n.sp[spi].W[k], 1, a_fwd, n.wscale[k]);
       g.bias = n.b[k]; g.sBias = d[k + 1];
       g.C = h->Hbuf[s][k + 1]; g.ldc = M * n.w[k + 1]; g.sC = n.w[k + 1];
       if (k == L - 2) {
@@ -502,7 +530,7 @@ int compute_mlp(ani_handle* h, hipStream_t st) {
       g.lda = M * n.w[k]; g.sA = n.w[k]; g.K = n.w[k];
       g.Bt = n.WT[k - 1]; g.ldb = n.w[k]; g.sB = (long long)d[k - 1] * n.w[k];
       g.N = d[k - 1];
-      g.Bt3 = n.WT3[k - 1]; g.kb3 = (g.K + 15) / 16; g.sB3 = (long long)split_bf16x3_elems(g.N, g.K);
+      set_planes(g, n.sp[spi].WT[k - 1], 1, a_bwd, n.wscale[k - 1]);
       g.C = h->Gbuf[s][k - 1]; g.ldc = M * n.w[k - 1]; g.sC = n.w[k - 1];
       probs.push_back(g);
     }
@@ -518,7 +546,7 @@ int compute_mlp(ani_handle* h, hipStream_t st) {
     g.A = h->Gbuf[s][1]; g.Amask = h->Hbuf[s][1]; g.lda = M * n.w[1]; g.K = M * n.w[1];
     g.Bt = n.WT0c ? n.WT0c : n.WT[0]; g.ldb = M * n.w[1];
     g.N = h->ap_run.aev_len;
-    g.Bt3 = n.WT0c ? n.WT0c3 : n.WT3[0]; g.kb3 = (g.K + 15) / 16; g.sB3 = 0;
+    set_planes(g, n.WT0c ? n.sp[spi].WT0c : n.sp[spi].WT[0], 0, a_bwd, n.wscale[0]);
     g.C = h->gaev.p + (size_t)h->row_start[s] * h->ap_run.aev_stride; g.ldc = h->ap_run.aev_stride;
     probs.push_back(g);
   }
@@ -535,15 +563,15 @@ int compute_mlp(ani_handle* h, hipStream_t st) {
   const int cslots = mlp_chain_slots(), lslots = cslots + cslots / 2;
   const bool chain_wins = tiles <= cslots || (tiles <= 2 * cslots &&   // beyond two rounds the two were within 4 %: launches
                                               0.106 * ((tiles + cslots - 1) / cslots) < 0.137 * ((tiles + lslots - 1) / lslots));
-  bool chain = h->mlp_chain && h->mlp_split && M == 1 && np > 0 && (h->mlp_chain > 1 || chain_wins);
+  bool chain = h->mlp_chain && arith != MLP_FP32 && M == 1 && np > 0 && (h->mlp_chain > 1 || chain_wins);
   for (const auto& lp : layer_probs) chain = chain && (int)lp.size() == np;
   if (chain) {
     std::vector<GemmArgs> flat;
     for (const auto& lp : layer_probs) flat.insert(flat.end(), lp.begin(), lp.end());
-    HIP_TRY(h, launch_mlp_chain(flat.data(), layer_epi.data(), (int)layer_probs.size(), np, &h->chain_plan, st));
+    HIP_TRY(h, launch_mlp_chain(flat.data(), layer_epi.data(), (int)layer_probs.size(), np, &h->chain_plan, st, arith));
   } else {
     for (size_t l = 0; l < layer_probs.size(); l++)
-      launch_gemm_group(layer_probs[l].data(), (int)layer_probs[l].size(), (Epilogue)layer_epi[l], st, h->mlp_split);
+      launch_gemm_group(layer_probs[l].data(), (int)layer_probs[l].size(), (Epilogue)layer_epi[l], st, arith);
   }
   return ANI_OK;
 }
@@ -818,10 +846,12 @@ void ani_destroy(ani_handle* h) {
     if (n.WT0c) (void)hipFree(n.WT0c);
     if (n.w_out) (void)hipFree(n.w_out);
     if (n.b_out) (void)hipFree(n.b_out);
-    for (unsigned short* p : n.W3) if (p) (void)hipFree(p);
-    for (unsigned short* p : n.WT3) if (p) (void)hipFree(p);
-    if (n.W0c3) (void)hipFree(n.W0c3);
-    if (n.WT0c3) (void)hipFree(n.WT0c3);
+    for (auto& sp : n.sp) {
+      for (unsigned short* p : sp.W) if (p) (void)hipFree(p);
+      for (unsigned short* p : sp.WT) if (p) (void)hipFree(p);
+      if (sp.W0c) (void)hipFree(sp.W0c);
+      if (sp.WT0c) (void)hipFree(sp.WT0c);
+    }
     for (double* p : n.W64) if (p) (void)hipFree(p);
     for (double* p : n.b64) if (p) (void)hipFree(p);
     for (double* p : n.WT64) if (p) (void)hipFree(p);
@@ -1095,8 +1125,13 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
     h->mlp_chain = value;
     return ANI_OK;
   }
-  if (strcmp(name, "mlp_split_bf16") == 0) {
-    h->mlp_split = value != 0;
+  if (strcmp(name, "mlp_arith") == 0) {
+    if (value < 0 || value > 2) { h->err = "mlp_arith must be 0 (fp32-input MFMA), 1 (bf16 x 3, exact) or 2 (fp16 x 2)"; return ANI_ERR_ARG; }
+    h->mlp_arith = (MlpArith)value;
+    return ANI_OK;
+  }
+  if (strcmp(name, "mlp_split_bf16") == 0) {   // earlier name: 1 = the exact bf16 split, 0 = fp32-input MFMA
+    h->mlp_arith = value != 0 ? MLP_BF16X3 : MLP_FP32;
     return ANI_OK;
   }
   if (strcmp(name, "device_overwrite_forces") == 0) {

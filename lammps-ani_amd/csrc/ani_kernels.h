@@ -37,17 +37,27 @@ struct GemmArgs {
   int batch;
   float scale;             // LAST: 1/num_models
   float alpha, inv_alpha;  // CELU
-  // split-bf16 path: Bt as three bf16 planes (x = hi + mid + lo exactly), blocked [kb3][N][3][16] with kb3 = ceil(K/16)
-  // 16-k blocks per row (zero padded); sB3 = per-batch stride in bf16 elements.  NULL: only the fp32 path can run.
-  const unsigned short* Bt3;
-  long long sB3;
-  int kb3;
+  // split paths: Bt as 16-bit planes -- three bf16 (x = hi + mid + lo exactly) or two fp16 (x 2^s = h + l to 2^-22) --
+  // blocked [kbp][N][planes][16] with kbp = ceil(K/16) 16-k blocks per row (zero padded); sBp = per-batch stride in
+  // 16-bit elements.  NULL: only the fp32 path can run.
+  const unsigned short* Btp;
+  long long sBp;
+  int kbp;
+  // two-term fp16 path: A is multiplied by a_scale (a power of two) while it is staged, the accumulators by
+  // inv_scale = 1 / (a_scale * scale of the weight planes) before the epilogue
+  float a_scale, inv_scale;
 };
+// arithmetic of the MLP products (ani_set_option "mlp_arith")
+enum MlpArith {
+  MLP_FP32 = 0,     // v_mfma_f32_32x32x2_f32
+  MLP_BF16X3 = 1,   // six v_mfma_f32_32x32x16_bf16 products of the exact three-way bf16 splits of both operands
+  MLP_F16X2 = 2     // three v_mfma_f32_32x32x16_f16 products of two-term fp16 splits of the scaled operands
+};
+inline int mlp_planes(MlpArith a) { return a == MLP_F16X2 ? 2 : 3; }
 void launch_gemm(const GemmArgs& g, Epilogue epi, hipStream_t st);
 // one launch for several problems of the same epilogue (all species buckets of one layer).
-// split_bf16 = true: fp32 products evaluated as six bf16 MFMA products of the exact three-way splits of both operands
-// (v_mfma_f32_32x32x16_bf16, fp32 accumulation); false: v_mfma_f32_32x32x2_f32.
-void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st, bool split_bf16 = false);
+// arith: see MlpArith; the problems' Btp / a_scale / inv_scale must have been set up for it
+void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st, MlpArith arith);
 // Small systems (about one 64-row tile per CU or less): the six products of the MLP as ONE launch.  A workgroup takes a
 // row tile through all layers in order — every layer of a tile reads only what the same workgroup wrote for the layer
 // before (activations go through global memory, L2-hot) — which removes five launch/drain gaps and the per-launch
@@ -59,13 +69,15 @@ struct ChainPlan {
   std::vector<unsigned char> host;
 };
 // returns the HIP status of the descriptor upload (a failed allocation must not let the step run on stale activations)
-hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st);
+hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st, MlpArith arith);
 void free_chain_plan(ChainPlan& p);
 int mlp_chain_slots();   // workgroups the chain kernel can keep resident (2 per CU)
 
-// dst[kb][N][3][16] bf16 planes of src[N][ld] (first K columns), kb = ceil(K/16); batch matrices src + i*s_src -> dst + i*N*kb*48
-void launch_split_bf16x3(const float* src, int batch, long long s_src, int N, int K, int ld, unsigned short* dst, hipStream_t st);
-inline size_t split_bf16x3_elems(int N, int K) { return (size_t)N * ((K + 15) / 16) * 48; }
+// dst[kb][N][planes][16] 16-bit planes of src[N][ld] (first K columns), kb = ceil(K/16); batch matrices src + i*s_src ->
+// dst + i*split_elems(N, K, arith).  scale: power of two applied to the weights of the fp16 path before they are split
+void launch_split_planes(const float* src, int batch, long long s_src, int N, int K, int ld, MlpArith arith, float scale,
+                         unsigned short* dst, hipStream_t st);
+inline size_t split_elems(int N, int K, MlpArith arith) { return (size_t)N * ((K + 15) / 16) * 16 * mlp_planes(arith); }
 
 // x (double [ntotal*3]) + species -> float4 {x,y,z,bits of cmap[species]}
 struct SpeciesMap { int m[kMaxSpecies]; };

@@ -299,7 +299,18 @@ __global__ __launch_bounds__(256, (WM == 4 ? 2 : (WM == 2 ? ANI_GEMM_LB2 : 3))) 
 // LDS image of a staged row: [hi 16 k | mid 16 k | lo 16 k] bf16 = 96 B + 16 B pad (stride 112 B: conflict-free
 // ds_read_b128).  K is walked in slabs of 16 (one MFMA k-block).
 // ---------------------------------------------------------------------------------------------------------------
+// Two-term fp16 variant (P = 2 below, the default: option "mlp_arith").  x * 2^s = h + l with two fp16 numbers, both
+// rounded to nearest: |x 2^s - h - l| <= 2^-22 |x 2^s| while l is a normal fp16 number (|x 2^s| >= 2^-3), 2^-25 absolute
+// below that -- which is why the operands are scaled by powers of two first (exact; undone on the accumulators, exact):
+// weights so that the largest of a layer sits below 2^13, activations by 2^4, gradients by 2^12 (GemmArgs::a_scale,
+// inv_scale).  Three v_mfma_f32_32x32x16_f16 products (hh, hl, lh; the dropped ll is below 2^-22 |a b|) instead of six:
+// operands good to 22-23 bits instead of 24, in sums whose fp32 accumulation over K = 128..1008 terms already carries
+// ~sqrt(K) 2^-24.  Against the fp64 oracle on the 100 002-atom box the forces are as close as with the exact split
+// (bench.py "parity"; tests/test_hip_properties.py).  Magnitudes beyond 65504 / scale (activations 4094, gradients 16
+// Hartree per unit) become inf and the energy NaN: loud, not wrong.  LDS row: [h 16 k | l 16 k] = 64 B + 16 B pad.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
   const unsigned xb = __float_as_uint(x);
@@ -310,15 +321,79 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
   l = __float_as_uint(r2);   // at most 8 significant bits left: its high half is exact
 }
 __device__ __forceinline__ unsigned pack_hi16(unsigned lo_elem, unsigned hi_elem) { return (lo_elem >> 16) | (hi_elem & 0xffff0000u); }
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& l) {   // two elements, packed
+  const f16x2 hv = {(_Float16)x0, (_Float16)x1};
+  const f16x2 lv = {(_Float16)(x0 - (float)hv[0]), (_Float16)(x1 - (float)hv[1])};
+  h = __builtin_bit_cast(unsigned, hv);
+  l = __builtin_bit_cast(unsigned, lv);
+}
+
+// P = planes of a staged operand: 3 = bf16 hi/mid/lo (exact), 2 = fp16 h/l of the scaled value
+template <int P>
+__device__ __forceinline__ void stage_a4(unsigned char* dst, float4 av, float a_scale) {   // four consecutive k of one row
+  if constexpr (P == 3) {
+    unsigned h[4], m[4], l[4];
+    split3(av.x, h[0], m[0], l[0]); split3(av.y, h[1], m[1], l[1]);
+    split3(av.z, h[2], m[2], l[2]); split3(av.w, h[3], m[3], l[3]);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+    *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+    *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+  } else {
+    unsigned h0, l0, h1, l1;
+    split2(av.x * a_scale, av.y * a_scale, h0, l0);
+    split2(av.z * a_scale, av.w * a_scale, h1, l1);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l0, l1);
+  }
+}
+template <int P>
+struct Frag { uint4 p[P]; };
+template <int P>
+__device__ __forceinline__ Frag<P> load_frag(const unsigned char* src) {
+  Frag<P> f;
+#pragma unroll
+  for (int i = 0; i < P; i++) f.p[i] = *reinterpret_cast<const uint4*>(src + 32 * i);
+  return f;
+}
+template <int P>
+__device__ __forceinline__ void mma_planes(const Frag<P>& a, const Frag<P>& b, f32x16& acc) {
+  if constexpr (P == 3) {   // smallest terms first
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.p[0]), am = __builtin_bit_cast(bf16x8, a.p[1]), al = __builtin_bit_cast(bf16x8, a.p[2]);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.p[0]), bm = __builtin_bit_cast(bf16x8, b.p[1]), bl = __builtin_bit_cast(bf16x8, b.p[2]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  } else {
+    const f16x8 ah = __builtin_bit_cast(f16x8, a.p[0]), al = __builtin_bit_cast(f16x8, a.p[1]);
+    const f16x8 bh = __builtin_bit_cast(f16x8, b.p[0]), bl = __builtin_bit_cast(f16x8, b.p[1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+  }
+}
+template <int P, int NTW>
+__device__ __forceinline__ void unscale(f32x16 (&acc)[NTW], float inv_scale) {
+  if constexpr (P == 2) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[nt][r] *= inv_scale;
+  }
+}
 
 // RT: 32-row strips per wave (register blocking in M).  The kernel is bound by LDS traffic, not by the MFMA pipe: with
 // RT = 2 every Bt fragment read from LDS feeds two row strips.
-template <int WM, int EPI, int KB, int RT>
+template <int WM, int EPI, int KB, int RT, int P>
 __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))) void gemm_grouped_x3(GroupArgs G) {
   constexpr int WN = 4 / WM;
   constexpr int R = 32 * WM * RT;
   constexpr int NTW = 8 / WN;
-  constexpr int ROW = KB * 96 + 16;   // bytes per staged row: KB k-blocks of [hi|mid|lo] x 16 k, + pad (112 / 208: conflict-free)
+  constexpr int PB = 32 * P;          // bytes of one k-block of a staged row
+  constexpr int ROW = KB * PB + 16;   // bytes per staged row: KB k-blocks of P planes x 16 k, + pad (112 / 80 B: conflict-free)
+  constexpr int NC = 2 * P;           // 16-byte chunks per row and k-block
   __shared__ uint4 lds4[(R + 256) * ROW / 16];
   unsigned char* As = reinterpret_cast<unsigned char*>(lds4);
   unsigned char* Bs = As + R * ROW;
@@ -350,8 +425,8 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
   const int tcnt = max(0, min(per, ntiles - t0));
 
   const float* __restrict__ A = g.A + (long long)b * g.sA + (long long)row0 * g.lda;
-  // Bt planes are stored k-block major, [kb][N][hi|mid|lo][16]: the slab of one k-block is contiguous over the rows
-  const uint4* __restrict__ B3 = reinterpret_cast<const uint4*>(g.Bt3 + (long long)b * g.sB3);
+  // Bt planes are stored k-block major, [kb][N][plane][16]: the slab of one k-block is contiguous over the rows
+  const uint4* __restrict__ B3 = reinterpret_cast<const uint4*>(g.Btp + (long long)b * g.sBp);
 
   f32x16 acc[RT][NTW];
 #pragma unroll
@@ -363,10 +438,10 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
 
   constexpr int PA = R >= 64 ? R / 64 : 1;   // A rows per thread
   float4 pa[PA][KB];
-  uint4 pb[6 * KB];
+  uint4 pb[NC * KB];
   const int ar = tid >> 2;          // A row (per 64-row group)
   const int ak = (tid & 3) * 4;     // k offset inside a k-block
-  const int brows = min(32 * ntiles, N - n0);   // Bt rows staged by this workgroup, as 6 * brows 16-byte chunks
+  const int brows = min(32 * ntiles, N - n0);   // Bt rows staged by this workgroup, as NC * brows 16-byte chunks
 
   // A (activations) streams from HBM / Infinity Cache, Bt (weights) from L2: A is fetched two slabs ahead, Bt one
   float4 pan[PA][KB], pm[PA][KB], pmn[PA][KB];
@@ -388,17 +463,17 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
   auto gloadB = [&](int kb0) {
 #pragma unroll
     for (int j = 0; j < KB; j++) {
-      const uint4* src = B3 + ((long long)(kb0 + j) * N + n0) * 6;
-      const bool bin = kb0 + j < g.kb3;
+      const uint4* src = B3 + ((long long)(kb0 + j) * N + n0) * NC;
+      const bool bin = kb0 + j < g.kbp;
 #pragma unroll
-      for (int i = 0; i < 6; i++) {
+      for (int i = 0; i < NC; i++) {
         const int c = tid + 256 * i;   // consecutive lanes, consecutive 16-byte chunks
-        pb[6 * j + i] = (bin && c < 6 * brows) ? src[c] : make_uint4(0, 0, 0, 0);
+        pb[NC * j + i] = (bin && c < NC * brows) ? src[c] : make_uint4(0, 0, 0, 0);
       }
     }
   };
 
-  const int nkt = (g.kb3 + KB - 1) / KB;
+  const int nkt = (g.kbp + KB - 1) / KB;
 #ifdef ANI_GEMM_NO_KROT
   const int rot = 0;
 #else
@@ -421,23 +496,17 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
             av.x *= dcelu_from_h(pm[i][j].x, g.inv_alpha); av.y *= dcelu_from_h(pm[i][j].y, g.inv_alpha);
             av.z *= dcelu_from_h(pm[i][j].z, g.inv_alpha); av.w *= dcelu_from_h(pm[i][j].w, g.inv_alpha);
           }
-          unsigned h[4], m[4], l[4];
-          split3(av.x, h[0], m[0], l[0]); split3(av.y, h[1], m[1], l[1]);
-          split3(av.z, h[2], m[2], l[2]); split3(av.w, h[3], m[3], l[3]);
-          unsigned char* dst = As + r * ROW + j * 96 + ak * 2;
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-          *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+          stage_a4<P>(As + r * ROW + j * PB + ak * 2, av, g.a_scale);
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < KB; j++)
 #pragma unroll
-      for (int i = 0; i < 6; i++) {
+      for (int i = 0; i < NC; i++) {
         const int c = tid + 256 * i;
-        const int r = c / 6, q = c - 6 * r;
-        if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + j * 96 + q * 16) = pb[6 * j + i];
+        const int r = c / NC, q = c - NC * r;
+        if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + j * PB + q * 16) = pb[NC * j + i];
       }
     __syncthreads();
 #ifndef ABLX_NO_GLOAD
@@ -450,40 +519,26 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
 #endif
 #pragma unroll
     for (int j = 0; j < KB; j++) {
-      bf16x8 ah[RT], am[RT], al[RT];
+      Frag<P> af[RT];
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) {
-        const unsigned char* ap = As + (32 * (wm * RT + rt) + lr) * ROW + j * 96 + lh * 16;
-        ah[rt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
-        am[rt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32));
-        al[rt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 64));
-      }
+      for (int rt = 0; rt < RT; rt++) af[rt] = load_frag<P>(As + (32 * (wm * RT + rt) + lr) * ROW + j * PB + lh * 16);
 #pragma unroll
       for (int nt = 0; nt < NTW; nt++) {
         if (nt < tcnt) {
-          const unsigned char* bp = Bs + (32 * (t0 + nt) + lr) * ROW + j * 96 + lh * 16;
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
-          const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
-          const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 64));
+          const Frag<P> bf = load_frag<P>(Bs + (32 * (t0 + nt) + lr) * ROW + j * PB + lh * 16);
 #ifdef ABLX_NO_MFMA
-          asm volatile("" ::"v"(ah[0]), "v"(am[0]), "v"(al[0]), "v"(bh), "v"(bm), "v"(bl));
+          asm volatile("" ::"v"(af[0].p[0]), "v"(af[0].p[1]), "v"(bf.p[0]), "v"(bf.p[1]));
           continue;
 #endif
 #pragma unroll
-          for (int rt = 0; rt < RT; rt++) {
-            // smallest terms first
-            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[rt], bm, acc[rt][nt], 0, 0, 0);
-            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, acc[rt][nt], 0, 0, 0);
-            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, acc[rt][nt], 0, 0, 0);
-            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[rt], bh, acc[rt][nt], 0, 0, 0);
-            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bm, acc[rt][nt], 0, 0, 0);
-            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][nt], 0, 0, 0);
-          }
+          for (int rt = 0; rt < RT; rt++) mma_planes<P>(af[rt], bf, acc[rt][nt]);
         }
       }
     }
   }
   __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) unscale<P>(acc[rt], g.inv_scale);
 #pragma unroll
   for (int rt = 0; rt < RT; rt++)
     gemm_epilogue<R, WN, EPI>(g, acc[rt], reinterpret_cast<float*>(lds4), b, n0, row0, t0, tcnt, wm * RT + rt, wn, lr, lh);
@@ -497,11 +552,11 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
 // CU, for systems with no more tiles than CUs: every tile streams all the weights from L2 (1.35 MB for the six ANI-2x
 // products of a species), so 32-row tiles for twice the workgroups doubled that traffic (5.9 TB/s at 12 500 atoms), while
 // a lone 4-wave workgroup on 64 rows ran each wave's instruction stream twice as long; eight waves halve both.
-template <int WM, int NWV>
+template <int WM, int NWV, int P>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const GemmArgs* __restrict__ layers, const int* __restrict__ epi,
                                                                            const int* __restrict__ tile_start, int nlayers, int nprob) {
-  constexpr int NT = 64 * NWV, WN = NWV / WM, R = 32 * WM, NTW = 8 / WN, ROW = 112;
-  constexpr int NB = 6 * 256 / NT;   // 16-byte chunks of a Bt slab per thread
+  constexpr int NT = 64 * NWV, WN = NWV / WM, R = 32 * WM, NTW = 8 / WN, ROW = 32 * P + 16, NC = 2 * P;
+  constexpr int NB = NC * 256 / NT;   // 16-byte chunks of a Bt slab per thread
   // two LDS stages: slab k+1 is written while slab k is multiplied and slab k+2 is in flight in registers -- one barrier
   // per slab, and every load has a whole slab to arrive.  (At most two of these workgroups share a CU.)
   constexpr int STAGE = (R + 256) * ROW;
@@ -523,8 +578,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const
     const int K = g.K, N = g.N;
     const float* __restrict__ A = g.A + (long long)row0 * g.lda;
     const float* __restrict__ Am = g.Amask ? g.Amask + (long long)row0 * g.lda : nullptr;
-    const uint4* __restrict__ B3 = reinterpret_cast<const uint4*>(g.Bt3);
-    const int nkt = g.kb3;
+    const uint4* __restrict__ B3 = reinterpret_cast<const uint4*>(g.Btp);
+    const int nkt = g.kbp;
     for (int n0 = 0; n0 < N; n0 += 256) {
       const int ntiles = min(8, (N - n0 + 31) >> 5);
       const int per = (ntiles + WN - 1) / WN;
@@ -546,11 +601,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const
         const bool in = kc < K && ar < R;
         q.pa = in ? *reinterpret_cast<const float4*>(A + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
         if (Am) q.pm = in ? *reinterpret_cast<const float4*>(Am + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
-        const uint4* src = B3 + ((long long)kb * N + n0) * 6;
+        const uint4* src = B3 + ((long long)kb * N + n0) * NC;
 #pragma unroll
         for (int i = 0; i < NB; i++) {
           const int c = tid + NT * i;
-          q.pb[i] = (kb < nkt && c < 6 * brows) ? src[c] : make_uint4(0, 0, 0, 0);
+          q.pb[i] = (kb < nkt && c < NC * brows) ? src[c] : make_uint4(0, 0, 0, 0);
         }
       };
       auto stage_write = [&](int st, const Regs& q) {
@@ -562,41 +617,24 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const
             av.x *= dcelu_from_h(q.pm.x, g.inv_alpha); av.y *= dcelu_from_h(q.pm.y, g.inv_alpha);
             av.z *= dcelu_from_h(q.pm.z, g.inv_alpha); av.w *= dcelu_from_h(q.pm.w, g.inv_alpha);
           }
-          unsigned h[4], m[4], lo[4];
-          split3(av.x, h[0], m[0], lo[0]); split3(av.y, h[1], m[1], lo[1]);
-          split3(av.z, h[2], m[2], lo[2]); split3(av.w, h[3], m[3], lo[3]);
-          unsigned char* dst = As + ar * ROW + ak * 2;
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-          *reinterpret_cast<uint2*>(dst + 32) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-          *reinterpret_cast<uint2*>(dst + 64) = make_uint2(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]));
+          stage_a4<P>(As + ar * ROW + ak * 2, av, g.a_scale);
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
           const int c = tid + NT * i;
-          const int r = c / 6, q6 = c - 6 * r;
+          const int r = c / NC, q6 = c - NC * r;
           if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + q6 * 16) = q.pb[i];
         }
       };
       auto multiply = [&](int st) {
         const unsigned char* As = lds + st * STAGE;
         const unsigned char* Bs = As + R * ROW;
-        const unsigned char* ap = As + (32 * wm + lr) * ROW + lh * 16;
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
-        const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 32));
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 64));
+        const Frag<P> af = load_frag<P>(As + (32 * wm + lr) * ROW + lh * 16);
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) {
           if (nt < tcnt) {
-            const unsigned char* bp = Bs + (32 * (t0 + nt) + lr) * ROW + lh * 16;
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp));
-            const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bp + 64));
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+            const Frag<P> bf = load_frag<P>(Bs + (32 * (t0 + nt) + lr) * ROW + lh * 16);
+            mma_planes<P>(af, bf, acc[nt]);
           }
         }
       };
@@ -618,6 +656,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const
         if (kt + 4 < nkt) gload(kt + 4, r1);
         __syncthreads();
       }
+      unscale<P>(acc, g.inv_scale);
       float* ldsf = reinterpret_cast<float*>(lds4);
       if (e == EPI_CELU) gemm_epilogue<R, WN, EPI_CELU>(g, acc, ldsf, 0, n0, row0, t0, tcnt, wm, wn, lr, lh);
       else if (e == EPI_LAST) gemm_epilogue<R, WN, EPI_LAST>(g, acc, ldsf, 0, n0, row0, t0, tcnt, wm, wn, lr, lh);
@@ -643,7 +682,7 @@ void free_chain_plan(ChainPlan& p) {
   p.d_desc = nullptr; p.bytes = 0; p.host.clear();
 }
 
-hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st) {
+hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st, MlpArith arith) {
   std::vector<int> tile_start(nprob + 1, 0);
   static const int forced_r = [] { const char* e = getenv("ANI_CHAIN_WAVES"); return e ? atoi(e) : 0; }();   // experiment knob: 4 / 8
   const int R = 64;
@@ -672,47 +711,56 @@ hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers,
   const unsigned char* d = reinterpret_cast<const unsigned char*>(plan->d_desc);
   // no more tiles than CUs: one eight-wave workgroup per CU; otherwise two four-wave workgroups per CU
   const bool wide = forced_r == 8 || (forced_r != 4 && 2 * total <= mlp_chain_slots());
-  if (wide)
-    hipLaunchKernelGGL((mlp_chain_x3<2, 8>), dim3(total), dim3(512), 0, st, reinterpret_cast<const GemmArgs*>(d),
+  auto go = [&](auto kernel, int threads) {
+    hipLaunchKernelGGL(kernel, dim3(total), dim3(threads), 0, st, reinterpret_cast<const GemmArgs*>(d),
                        reinterpret_cast<const int*>(d + b0), reinterpret_cast<const int*>(d + b0 + b1), nlayers, nprob);
-  else
-    hipLaunchKernelGGL((mlp_chain_x3<2, 4>), dim3(total), dim3(256), 0, st, reinterpret_cast<const GemmArgs*>(d),
-                       reinterpret_cast<const int*>(d + b0), reinterpret_cast<const int*>(d + b0 + b1), nlayers, nprob);
+  };
+  if (arith == MLP_F16X2) { if (wide) go(mlp_chain_x3<2, 8, 2>, 512); else go(mlp_chain_x3<2, 4, 2>, 256); }
+  else { if (wide) go(mlp_chain_x3<2, 8, 3>, 512); else go(mlp_chain_x3<2, 4, 3>, 256); }
   return hipGetLastError();
 }
 
-// weights -> blocked bf16 planes
-__global__ void split_bf16x3_kernel(const float* __restrict__ src, long long s_src, int N, int K, int ld, int kb,
-                                    unsigned short* __restrict__ dst) {
+// weights -> blocked planes: three bf16 (planes = 3) or two fp16 of the scaled weight (planes = 2)
+__global__ void split_planes_kernel(const float* __restrict__ src, long long s_src, int N, int K, int ld, int kb, int planes,
+                                    float scale, unsigned short* __restrict__ dst) {
   const long long per = (long long)N * kb * 16;   // (row, k) slots per matrix
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int bi = blockIdx.y;
   if (idx >= per) return;
   const int n = (int)(idx / (kb * 16)), k = (int)(idx % (kb * 16));
   const float x = k < K ? src[(long long)bi * s_src + (long long)n * ld + k] : 0.f;
-  unsigned h, m, l;
-  split3(x, h, m, l);
-  unsigned short* d = dst + (long long)bi * per * 3 + ((long long)(k / 16) * N + n) * 48 + (k % 16);
-  d[0] = (unsigned short)(h >> 16);
-  d[16] = (unsigned short)(m >> 16);
-  d[32] = (unsigned short)(l >> 16);
+  unsigned short* d = dst + ((long long)bi * per + ((long long)(k / 16) * N + n) * 16) * planes + (k % 16);
+  if (planes == 3) {
+    unsigned h, m, l;
+    split3(x, h, m, l);
+    d[0] = (unsigned short)(h >> 16);
+    d[16] = (unsigned short)(m >> 16);
+    d[32] = (unsigned short)(l >> 16);
+  } else {
+    unsigned h, l;
+    split2(x * scale, 0.f, h, l);
+    d[0] = (unsigned short)(h & 0xffffu);
+    d[16] = (unsigned short)(l & 0xffffu);
+  }
 }
 
-void launch_split_bf16x3(const float* src, int batch, long long s_src, int N, int K, int ld, unsigned short* dst, hipStream_t st) {
+void launch_split_planes(const float* src, int batch, long long s_src, int N, int K, int ld, MlpArith arith, float scale,
+                         unsigned short* dst, hipStream_t st) {
   const int kb = (K + 15) / 16;
   const long long per = (long long)N * kb * 16;
   if (per <= 0 || batch <= 0) return;
-  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((per + 255) / 256), batch), dim3(256), 0, st, src, s_src, N, K, ld, kb, dst);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((per + 255) / 256), batch), dim3(256), 0, st, src, s_src, N, K, ld, kb,
+                     mlp_planes(arith), scale, dst);
 }
 
-template <int WM, int KB, int RT>
+template <int WM, int KB, int RT, int P>
 static void launch_wm_x3(const GroupArgs& G, Epilogue epi, int total, hipStream_t st) {
   const dim3 grid(total), block(256);
   switch (epi) {
-    case EPI_PLAIN: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_PLAIN, KB, RT>), grid, block, 0, st, G); break;
-    case EPI_CELU: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_CELU, KB, RT>), grid, block, 0, st, G); break;
-    case EPI_LAST: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_LAST, KB, RT>), grid, block, 0, st, G); break;
-    case EPI_BWD: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_BWD, KB, RT>), grid, block, 0, st, G); break;
+    case EPI_PLAIN: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_PLAIN, KB, RT, P>), grid, block, 0, st, G); break;
+    case EPI_CELU: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_CELU, KB, RT, P>), grid, block, 0, st, G); break;
+    case EPI_LAST: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_LAST, KB, RT, P>), grid, block, 0, st, G); break;
+    case EPI_BWD: hipLaunchKernelGGL((gemm_grouped_x3<WM, EPI_BWD, KB, RT, P>), grid, block, 0, st, G); break;
   }
 }
 
@@ -745,7 +793,8 @@ static double makespan(const GemmArgs* probs, int nprob, int R, int ncu) {
   return total / (ncu * eff) + biggest;
 }
 
-void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st, bool split_bf16) {
+void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream_t st, MlpArith arith) {
+  const bool split_bf16 = arith != MLP_FP32;
   static const int forced = [] { const char* e = getenv("ANI_GEMM_WM"); return e ? atoi(e) : 0; }();
   static const int ncu = [] {
     int dev = 0, n = 256;
@@ -781,18 +830,17 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
     G.tile_start[G.nprob] = total;
     if (total == 0) continue;
     bool x3 = split_bf16;
-    for (int i = 0; i < G.nprob; i++) x3 = x3 && G.p[i].Bt3 != nullptr;
+    for (int i = 0; i < G.nprob; i++) x3 = x3 && G.p[i].Btp != nullptr;
     if (x3) {
-      static const int kbf = [] { const char* e = getenv("ANI_GEMM_KB"); return e ? atoi(e) : 1; }();
       // 128-row tiles: 2x2 waves with two row strips each (RT = 2), not four waves stacked in M
-      if (kbf == 2) {
-        if (WM == 4) launch_wm_x3<2, 2, 2>(G, epi, total, st);
-        else if (WM == 2) launch_wm_x3<2, 2, 1>(G, epi, total, st);
-        else launch_wm_x3<1, 2, 1>(G, epi, total, st);
+      if (arith == MLP_F16X2) {
+        if (WM == 4) launch_wm_x3<2, 1, 2, 2>(G, epi, total, st);
+        else if (WM == 2) launch_wm_x3<2, 1, 1, 2>(G, epi, total, st);
+        else launch_wm_x3<1, 1, 1, 2>(G, epi, total, st);
       } else {
-        if (WM == 4) launch_wm_x3<2, 1, 2>(G, epi, total, st);
-        else if (WM == 2) launch_wm_x3<2, 1, 1>(G, epi, total, st);
-        else launch_wm_x3<1, 1, 1>(G, epi, total, st);
+        if (WM == 4) launch_wm_x3<2, 1, 2, 3>(G, epi, total, st);
+        else if (WM == 2) launch_wm_x3<2, 1, 1, 3>(G, epi, total, st);
+        else launch_wm_x3<1, 1, 1, 3>(G, epi, total, st);
       }
     } else {
       if (WM == 4) launch_wm<4>(G, epi, total, st);
@@ -802,6 +850,6 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
   }
 }
 
-void launch_gemm(const GemmArgs& g, Epilogue epi, hipStream_t st) { launch_gemm_group(&g, 1, epi, st); }
+void launch_gemm(const GemmArgs& g, Epilogue epi, hipStream_t st) { launch_gemm_group(&g, 1, epi, st, MLP_FP32); }
 
 }  // namespace ani

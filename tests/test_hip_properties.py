@@ -123,26 +123,60 @@ def test_argument_errors(model_cache, hip):
     ani.close()
 
 
-def test_split_bf16_mlp_is_as_accurate_as_fp32_input_mfma(model_cache, hip):
-    """The default MLP path evaluates every fp32 product as six bf16 MFMA products of the exact hi/mid/lo splits of both
-    operands.  Against the fp64 oracle it must be as good as the fp32-input MFMA path (option mlp_split_bf16 = 0), and
-    the two must agree far inside the force tolerance; same for the full 8-member ensemble on a mixed-species box."""
+def test_split_mlp_arithmetics_are_as_accurate_as_fp32_input_mfma(model_cache, hip):
+    """The MLP evaluates its fp32 products on the 16-bit MFMA pipe (option mlp_arith): 2 (default) = three fp16 products of
+    two-term splits of the power-of-two scaled operands (operands good to 2^-22), 1 = six bf16 products of the exact
+    three-term splits, 0 = the fp32-input MFMA instruction.  Against the fp64 oracle each split path must be as good as
+    the fp32-input one -- forces AND per-atom energies, max and rms -- and all must agree with each other far inside the
+    force tolerance; water with one member (chained launch and per-layer launches) and the full 8-member ensemble on a
+    mixed-species box."""
     from oracle import Oracle
-    for kind, nm, inp in (("ani2x", 1, hx.decompose(hx.water_box(1500, seed=5))),
-                          ("ani2x", 8, hx.decompose(hx.random_box(700, 7, 22.0, seed=9)))):
+    for kind, nm, inp, chain in (("ani2x", 1, hx.decompose(hx.water_box(1500, seed=5)), 1),
+                                 ("ani2x", 1, hx.decompose(hx.water_box(1500, seed=5)), 0),
+                                 ("ani2x", 8, hx.decompose(hx.random_box(700, 7, 22.0, seed=9)), 1)):
         p = model_cache(kind, nm, 2024)
         ref = Oracle(p).compute(inp)
         ani = hip.ANI(p, 0)
-        a = ani.compute(inp, ago=0)
-        ani.set_option("mlp_split_bf16", 0)
-        b = ani.compute(inp, ago=0)
-        ea, eb = np.abs(a["force"] - ref["force"]).max(), np.abs(b["force"] - ref["force"]).max()
-        print(f"{kind} x{nm}: max|dF| split {ea:.2e}, fp32-input {eb:.2e}, between them {np.abs(a['force'] - b['force']).max():.2e}")
-        assert ea < F_TOL and eb < F_TOL
-        assert ea < 2.0 * eb + 1e-5
-        assert np.abs(a["force"] - b["force"]).max() < 0.25 * F_TOL
-        assert abs(a["energy"] - b["energy"]) < 1e-3 * max(1.0, inp.nlocal / 100.0)
+        ani.set_option("mlp_chain", chain)
+        out, err, rms, eat = {}, {}, {}, {}
+        for arith in (2, 1, 0):
+            ani.set_option("mlp_arith", arith)
+            out[arith] = ani.compute(inp, ago=0)
+            d = out[arith]["force"] - ref["force"]
+            err[arith], rms[arith] = np.abs(d).max(), np.sqrt((d ** 2).mean())
+            eat[arith] = np.abs(out[arith]["eatom"] - ref["eatom"][: inp.nlocal]).max()
+        print(f"{kind} x{nm} chain={chain}: max|dF| f16x2 {err[2]:.2e} bf16x3 {err[1]:.2e} fp32 {err[0]:.2e}; rms {rms[2]:.2e} {rms[1]:.2e} "
+              f"{rms[0]:.2e}; max|dE_atom| {eat[2]:.2e} {eat[1]:.2e} {eat[0]:.2e}")
+        for arith in (2, 1):
+            assert err[arith] < F_TOL and err[0] < F_TOL
+            assert err[arith] < 1.5 * err[0] + 1e-5 and rms[arith] < 1.25 * rms[0] + 1e-6
+            assert eat[arith] < 1.5 * eat[0] + 2e-5
+            assert np.abs(out[arith]["force"] - out[0]["force"]).max() < 0.25 * F_TOL
+            assert abs(out[arith]["energy"] - out[0]["energy"]) < 1e-3 * max(1.0, inp.nlocal / 100.0)
         ani.close()
+
+
+def test_fp16_split_overflow_is_loud(model_cache, hip, tmp_path):
+    """The two-term fp16 path scales activations by 2^4: a hidden activation beyond 4094 is outside fp16's range and must
+    surface as a non-finite energy (which the entry points report), never as a finite wrong one.  Built by blowing up a
+    first-layer bias of a synthetic model; the exact bf16 path evaluates the same model finitely."""
+    from lammps_ani_amd import model_file as mf
+    m = mf.synthetic_model("ani2x", 1, seed=2024)
+    for s in range(len(m.species)):
+        m.weights[0][s][0][1][:] = 1.0e4        # bias of layer 0: every activation of layer 1 ~ 1e4
+    p = str(tmp_path / "big.anim")
+    mf.write_model(p, m)
+    inp = hx.decompose(hx.water_box(600, seed=5))
+    ani = hip.ANI(p, 0)
+    ani.set_option("mlp_arith", 1)
+    assert np.isfinite(ani.compute(inp, ago=0)["energy"])
+    ani.set_option("mlp_arith", 2)
+    try:
+        e = ani.compute(inp, ago=0)["energy"]
+    except hip.AniError:
+        e = float("nan")
+    assert not np.isfinite(e)
+    ani.close()
 
 
 def test_screened_radial_capacity_overflow_is_loud_and_option_restores_it(model_cache, hip):
