@@ -38,6 +38,13 @@ PUBLISHED_NS_DAY = {1: 1.495, 2: 2.774, 4: 4.846, 8: 7.663}
 KERNEL_SOURCES = ("ani_kernels_aev.hip", "ani_kernels_mlp.hip", "ani_kernels_misc.hip", "ani_hip.cpp", "ani_kernels.h")
 
 
+def apply_env_options(ani):
+    """Development knob: ANI_BENCH_OPTIONS="name=value,..." is passed to ani_set_option on every handle the bench makes."""
+    for kv in filter(None, os.environ.get("ANI_BENCH_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        ani.set_option(k.strip(), int(v))
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +184,7 @@ def main():
             self.grid = comm.grid_for(world)
             self.inp = inp = hx.decompose(self.system, self.grid, rank, cutoff=5.1, skin=2.0)
             self.ani = ani_hip.ANI(self.mpath, dev_index, -1, use_cuaev=(args.aev == "cuaev"), use_fullnbr=True, use_single=True)
+            apply_env_options(self.ani)
             self.d_x = torch.from_numpy(inp.x.reshape(-1)).to(dev)
             self.d_species = torch.from_numpy(inp.species.astype(np.int32)).to(dev)
             self.d_ilist = torch.from_numpy(inp.ilist).to(dev)
@@ -228,6 +236,7 @@ def main():
         grid = comm.grid_for(world)
         inp = hx.decompose(system, grid, rank, cutoff=5.1, skin=2.0)
         ani = ani_hip.ANI(path, dev_index, -1, use_cuaev=(args.aev == "cuaev"), use_fullnbr=True, use_single=True)
+        apply_env_options(ani)
         if args.dense_aev:
             ani.set_option("prune_absent_species", 0)
         run = md.VerletRun(ani, inp, system.boxhi - system.boxlo, dev, dt=0.5, langevin=(300.0, 100.0), box_lo=system.boxlo, grid=grid)

@@ -552,11 +552,14 @@ __global__ __launch_bounds__(256, ((KB == 2 || RT == 2) ? 2 : (WM == 4 ? 2 : 3))
 // CU, for systems with no more tiles than CUs: every tile streams all the weights from L2 (1.35 MB for the six ANI-2x
 // products of a species), so 32-row tiles for twice the workgroups doubled that traffic (5.9 TB/s at 12 500 atoms), while
 // a lone 4-wave workgroup on 64 rows ran each wave's instruction stream twice as long; eight waves halve both.
-template <int WM, int NWV, int P>
+// KB: k-blocks (16 k each) per slab.  The lone eight-wave workgroup of a small system is bound by the length of its
+// chain of slab steps (load -> LDS -> barrier -> fragments -> MFMA), not by any throughput: KB = 2 halves the steps.
+template <int WM, int NWV, int P, int KB>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const GemmArgs* __restrict__ layers, const int* __restrict__ epi,
                                                                            const int* __restrict__ tile_start, int nlayers, int nprob) {
-  constexpr int NT = 64 * NWV, WN = NWV / WM, R = 32 * WM, NTW = 8 / WN, ROW = 32 * P + 16, NC = 2 * P;
-  constexpr int NB = NC * 256 / NT;   // 16-byte chunks of a Bt slab per thread
+  constexpr int NT = 64 * NWV, WN = NWV / WM, R = 32 * WM, NTW = 8 / WN, PB = 32 * P, ROW = KB * PB + 16, NC = 2 * P;
+  constexpr int NB = NC * 256 / NT;   // 16-byte chunks of one k-block of a Bt slab per thread
+  constexpr int AL = (R * 4 * KB + NT - 1) / NT;   // float4 items of an A slab (row, k-block, 4 k) per thread
   // two LDS stages: slab k+1 is written while slab k is multiplied and slab k+2 is in flight in registers -- one barrier
   // per slab, and every load has a whole slab to arrive.  (At most two of these workgroups share a CU.)
   constexpr int STAGE = (R + 256) * ROW;
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const
   const int wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  const int ar = tid >> 2, ak = (tid & 3) * 4;
+  const int ak = (tid & 3) * 4;
 
   for (int l = 0; l < nlayers; l++) {
     const GemmArgs g = layers[l * nprob + pi];
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const
     const float* __restrict__ A = g.A + (long long)row0 * g.lda;
     const float* __restrict__ Am = g.Amask ? g.Amask + (long long)row0 * g.lda : nullptr;
     const uint4* __restrict__ B3 = reinterpret_cast<const uint4*>(g.Btp);
-    const int nkt = g.kbp;
+    const int nkt = (g.kbp + KB - 1) / KB;
     for (int n0 = 0; n0 < N; n0 += 256) {
       const int ntiles = min(8, (N - n0 + 31) >> 5);
       const int per = (ntiles + WN - 1) / WN;
@@ -594,47 +597,65 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const
       // Two register sets of loads in flight: the set written to LDS in step kt was requested in step kt - 2.  A lone
       // workgroup per CU (small systems) is bound by the latency of these loads, not by the matrix pipe: with one set
       // (one slab of lead) a slab took ~1.2 us whatever the tile height.
-      struct Regs { float4 pa, pm; uint4 pb[NB]; };
+      struct Regs { float4 pa[AL], pm[AL]; uint4 pb[KB][NB]; };
       Regs r0, r1;
-      auto gload = [&](int kb, Regs& q) {
-        const int kc = kb * 16 + ak;
-        const bool in = kc < K && ar < R;
-        q.pa = in ? *reinterpret_cast<const float4*>(A + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
-        if (Am) q.pm = in ? *reinterpret_cast<const float4*>(Am + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
-        const uint4* src = B3 + ((long long)kb * N + n0) * NC;
+      // item id of an A slab: 4-k chunk (id & 3), row (id >> 2) % R, k-block id / (4 R)
+      auto gload = [&](int kt, Regs& q) {
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-          const int c = tid + NT * i;
-          q.pb[i] = (kb < nkt && c < NC * brows) ? src[c] : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < AL; i++) {
+          const int id = tid + NT * i, ar = (id >> 2) % R, j = id / (4 * R);
+          const int kc = (kt * KB + j) * 16 + ak;
+          const bool in = kc < K && j < KB;
+          q.pa[i] = in ? *reinterpret_cast<const float4*>(A + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
+          if (Am) q.pm[i] = in ? *reinterpret_cast<const float4*>(Am + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < KB; j++) {
+          const int kb = kt * KB + j;
+          const uint4* src = B3 + ((long long)kb * N + n0) * NC;
+#pragma unroll
+          for (int i = 0; i < NB; i++) {
+            const int c = tid + NT * i;
+            q.pb[j][i] = (kb < g.kbp && c < NC * brows) ? src[c] : make_uint4(0, 0, 0, 0);
+          }
         }
       };
       auto stage_write = [&](int st, const Regs& q) {
         unsigned char* As = lds + st * STAGE;
         unsigned char* Bs = As + R * ROW;
-        if (ar < R) {
-          float4 av = q.pa;
-          if (Am) {
-            av.x *= dcelu_from_h(q.pm.x, g.inv_alpha); av.y *= dcelu_from_h(q.pm.y, g.inv_alpha);
-            av.z *= dcelu_from_h(q.pm.z, g.inv_alpha); av.w *= dcelu_from_h(q.pm.w, g.inv_alpha);
+#pragma unroll
+        for (int i = 0; i < AL; i++) {
+          const int id = tid + NT * i, ar = (id >> 2) % R, j = id / (4 * R);
+          if (j < KB) {
+            float4 av = q.pa[i];
+            if (Am) {
+              av.x *= dcelu_from_h(q.pm[i].x, g.inv_alpha); av.y *= dcelu_from_h(q.pm[i].y, g.inv_alpha);
+              av.z *= dcelu_from_h(q.pm[i].z, g.inv_alpha); av.w *= dcelu_from_h(q.pm[i].w, g.inv_alpha);
+            }
+            stage_a4<P>(As + ar * ROW + j * PB + ak * 2, av, g.a_scale);
           }
-          stage_a4<P>(As + ar * ROW + ak * 2, av, g.a_scale);
         }
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-          const int c = tid + NT * i;
-          const int r = c / NC, q6 = c - NC * r;
-          if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + q6 * 16) = q.pb[i];
-        }
+        for (int j = 0; j < KB; j++)
+#pragma unroll
+          for (int i = 0; i < NB; i++) {
+            const int c = tid + NT * i;
+            const int r = c / NC, q6 = c - NC * r;
+            if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + j * PB + q6 * 16) = q.pb[j][i];
+          }
       };
       auto multiply = [&](int st) {
         const unsigned char* As = lds + st * STAGE;
         const unsigned char* Bs = As + R * ROW;
-        const Frag<P> af = load_frag<P>(As + (32 * wm + lr) * ROW + lh * 16);
 #pragma unroll
-        for (int nt = 0; nt < NTW; nt++) {
-          if (nt < tcnt) {
-            const Frag<P> bf = load_frag<P>(Bs + (32 * (t0 + nt) + lr) * ROW + lh * 16);
-            mma_planes<P>(af, bf, acc[nt]);
+        for (int j = 0; j < KB; j++) {
+          const Frag<P> af = load_frag<P>(As + (32 * wm + lr) * ROW + j * PB + lh * 16);
+#pragma unroll
+          for (int nt = 0; nt < NTW; nt++) {
+            if (nt < tcnt) {
+              const Frag<P> bf = load_frag<P>(Bs + (32 * (t0 + nt) + lr) * ROW + j * PB + lh * 16);
+              mma_planes<P>(af, bf, acc[nt]);
+            }
           }
         }
       };
@@ -715,8 +736,14 @@ hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers,
     hipLaunchKernelGGL(kernel, dim3(total), dim3(threads), 0, st, reinterpret_cast<const GemmArgs*>(d),
                        reinterpret_cast<const int*>(d + b0), reinterpret_cast<const int*>(d + b0 + b1), nlayers, nprob);
   };
-  if (arith == MLP_F16X2) { if (wide) go(mlp_chain_x3<2, 8, 2>, 512); else go(mlp_chain_x3<2, 4, 2>, 256); }
-  else { if (wide) go(mlp_chain_x3<2, 8, 3>, 512); else go(mlp_chain_x3<2, 4, 3>, 256); }
+  static const int kb_wide = [] { const char* e = getenv("ANI_CHAIN_KB"); return e ? atoi(e) : 2; }();   // experiment knob
+  if (arith == MLP_F16X2) {
+    if (wide && kb_wide == 2) go(mlp_chain_x3<2, 8, 2, 2>, 512);
+    else if (wide) go(mlp_chain_x3<2, 8, 2, 1>, 512);
+    else go(mlp_chain_x3<2, 4, 2, 1>, 256);
+  } else {
+    if (wide) go(mlp_chain_x3<2, 8, 3, 1>, 512); else go(mlp_chain_x3<2, 4, 3, 1>, 256);
+  }
   return hipGetLastError();
 }
 

@@ -355,7 +355,8 @@ def test_local_rank_maps_onto_the_visible_devices(model_cache, hip):
         if local_rank % ndev == 0:
             if ref is None:
                 ref = out
-            assert np.array_equal(out["force"], ref["force"]) and out["energy"] == ref["energy"]   # same device, same bits
+            # same device, same arithmetic; only the order of the fp32 force atomics differs between runs
+            assert np.abs(out["force"] - ref["force"]).max() < 1e-4 and abs(out["energy"] - ref["energy"]) < 1e-4
         else:
             assert np.abs(out["force"] - ref["force"]).max() < F_TOL
         ani.close()
