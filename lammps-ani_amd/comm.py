@@ -177,8 +177,11 @@ class DomainComm:
         self._dest = torch.tensor([t[0] for t in full], dtype=torch.long, device=device)
         self._cidx = [torch.tensor([t[1 + d] for t in full], dtype=torch.long, device=device) for d in range(3)]
         self._shift = torch.tensor([[t[4], t[5], t[6]] for t in full], dtype=torch.float64, device=device) * self.box_len
-        self._lo = [torch.tensor([c[2] for c in combos[d]], dtype=torch.float64, device=device)[:, None] for d in range(3)]
-        self._hi = [torch.tensor([c[3] for c in combos[d]], dtype=torch.float64, device=device)[:, None] for d in range(3)]
+        # [combos, 1, 3]: interval of the unshifted position that combination accepts
+        self._clo = torch.tensor([[combos[d][t[1 + d]][2] for d in range(3)] for t in full], dtype=torch.float64,
+                                 device=device).reshape(-1, 1, 3)
+        self._chi = torch.tensor([[combos[d][t[1 + d]][3] for d in range(3)] for t in full], dtype=torch.float64,
+                                 device=device).reshape(-1, 1, 3)
         self.nlocal = 0
         self.nghost = 0
         self.send_idx = torch.zeros(0, dtype=torch.long, device=device)
@@ -214,11 +217,15 @@ class DomainComm:
         Wraps positions into the box (Domain::pbc) and hands every atom to the rank whose brick now holds it.
         Returns the new (x, *per_atom) of this rank; atoms that stay keep their relative order."""
         L, lo = self.box_len, self.box_lo
-        x = x.clone()
-        for d in range(3):
-            if self.periodic[d]:
-                x[:, d] -= torch.floor((x[:, d] - lo[d]) / L[d]) * L[d]
-                x[:, d] = torch.where(x[:, d] >= lo[d] + L[d], lo[d], x[:, d])
+        if all(self.periodic):
+            x = x - torch.floor((x - lo) / L) * L
+            x = torch.where(x >= lo + L, lo.expand_as(x), x)   # a coordinate that rounds up onto the upper face
+        else:
+            x = x.clone()
+            for d in range(3):
+                if self.periodic[d]:
+                    x[:, d] -= torch.floor((x[:, d] - lo[d]) / L[d]) * L[d]
+                    x[:, d] = torch.where(x[:, d] >= lo[d] + L[d], lo[d], x[:, d])
         if self.world == 1:
             return (x,) + tuple(per_atom)
         P = torch.tensor(self.grid, dtype=torch.float64, device=x.device)
@@ -239,15 +246,18 @@ class DomainComm:
         rank itself, for periodic self-images) needs as ghosts, exchanges it, and returns (x_all, species_all) with the
         ghosts appended."""
         n = x.shape[0]
-        m = []
-        for d in range(3):
-            xd = x[:, d][None, :]
-            m.append((xd >= self._lo[d]) & (xd < self._hi[d]))          # [combos_d, n]
-        mask = m[0][self._cidx[0]] & m[1][self._cidx[1]] & m[2][self._cidx[2]]   # [combos, n]
-        hit = mask.nonzero()                                           # combo-major, atoms ascending
+        if self._dest.numel() == 0:
+            hit = torch.zeros((0, 2), dtype=torch.long, device=x.device)
+        else:
+            xb = x[None, :, :]
+            mask = ((xb >= self._clo) & (xb < self._chi)).all(dim=2)   # [combos, n]
+            hit = mask.nonzero()                                       # combo-major, atoms ascending
         self.send_idx = hit[:, 1].contiguous()
         self.send_shift = self._shift[hit[:, 0]]
-        send = torch.bincount(self._dest[hit[:, 0]], minlength=self.world).cpu().tolist()
+        if self.world == 1:
+            send = [int(hit.shape[0])]
+        else:
+            send = torch.bincount(self._dest[hit[:, 0]], minlength=self.world).cpu().tolist()
         self.send_splits = send
         self.recv_splits = self._counts(send)
         self.nlocal = n

@@ -92,16 +92,22 @@ class VerletRun:
         """mass-dependent factors of the integrator, expanded once per re-neighbouring (atoms may have migrated) so
         that each update is ONE fused device kernel"""
         n = self.nlocal
+        if self.dc.world == 1 and getattr(self, "_factors_n", -1) == n:
+            return   # one rank: nobody migrates, the owned atoms keep their order
+        self._factors_n = n
         m = self.masses[self.species[:n].long()]
         self.mass = m[:, None]
-        self._dtfm1 = ((0.5 * self.dt * FTM2V) / m).contiguous()          # [n], the fused kernels' form
-        self._dtf_over_m = self._dtfm1[:, None].expand(-1, 3).contiguous()
+        self._dtfm1 = (0.5 * self.dt * FTM2V) / m                        # [n], the fused kernels' form
         self._lang = None
         self._g1 = self._g2 = None
         if self.langevin is not None:
             T, damp = self.langevin
-            self._g1 = (-m / damp / FTM2V).contiguous()
-            self._g2 = (torch.sqrt(m) * (24.0 * BOLTZ * T / damp / self.dt / MVV2E) ** 0.5 / FTM2V).contiguous()
+            self._g1 = m * (-1.0 / damp / FTM2V)
+            self._g2 = torch.sqrt(m) * ((24.0 * BOLTZ * T / damp / self.dt / MVV2E) ** 0.5 / FTM2V)
+        if self._fused:
+            return   # the [n, 3] forms below are the operands of the tensor-operation steps only
+        self._dtf_over_m = self._dtfm1[:, None].expand(-1, 3).contiguous()
+        if self.langevin is not None:
             self._lang = (self._g1[:, None].expand(-1, 3).contiguous(), self._g2[:, None].expand(-1, 3).contiguous(),
                           torch.empty((n, 3), dtype=torch.float64, device=self.device))
 
@@ -145,8 +151,12 @@ class VerletRun:
     def _post_force(self):
         """fix langevin (LAMMPS fix_langevin.cpp, uniform random numbers in [-0.5, 0.5)): f += g1 v + g2 r on owned atoms.
         Tensor-operation form: set-up, and devices without the fused kernels (step() fuses it with final_integrate)."""
-        if self._lang is not None:
-            g1, g2, r = self._lang
+        if self._g1 is not None:
+            if self._lang is not None:
+                g1, g2, r = self._lang
+            else:   # fused mode keeps only the [n] factors: this form runs once, at set-up
+                g1, g2 = self._g1[:, None], self._g2[:, None]
+                r = torch.empty((self.nlocal, 3), dtype=torch.float64, device=self.device)
             r.uniform_(-0.5, 0.5, generator=self.gen)
             fl = self.f[: self.nlocal]
             fl.addcmul_(g1, self.v)
