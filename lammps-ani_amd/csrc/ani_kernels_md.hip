@@ -25,10 +25,18 @@ __global__ __launch_bounds__(256) void initial_integrate_kernel(double* __restri
       d2 += d * d;
     }
   }
-  // wave maximum, then one atomic per wave; non-negative doubles order like their bit patterns
+  // workgroup maximum, then at most one atomic per workgroup -- and none once the running maximum is larger (it only
+  // grows between two looks of the host: a stale read costs an atomic, never a missed one).  1 563 same-address atomics
+  // made this kernel 21 us at 100 002 atoms.  Non-negative doubles order like their bit patterns.
   for (int off = 32; off > 0; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off));
-  if ((threadIdx.x & 63) == 0 && d2 > 0.0)
-    atomicMax(reinterpret_cast<unsigned long long*>(d2max), (unsigned long long)__double_as_longlong(d2));
+  __shared__ double wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = d2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    d2 = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    if (d2 > *reinterpret_cast<volatile double*>(d2max))
+      atomicMax(reinterpret_cast<unsigned long long*>(d2max), (unsigned long long)__double_as_longlong(d2));
+  }
 }
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {   // splitmix64 finaliser
