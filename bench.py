@@ -371,7 +371,10 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": (ns_day / PUBLISHED_NS_DAY[world]) if (not args.no_md and (args.atoms, args.models) == (100002, 1) and world in PUBLISHED_NS_DAY) else None,
             "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 in/out and accumulation everywhere; MLP products via exact 3-way bf16 operand splits (6 MFMA terms); fp64 positions, velocities, energy sums",
+            "dtype_note": "fp32 in/out and accumulation everywhere; the MLP's fp32 products are evaluated as three fp16 MFMA products of "
+                          "two-term splits of the power-of-two scaled operands (operands to 2^-22; `parity` compares the forces of this, "
+                          "of the exact six-product bf16 split and of the fp32-input MFMA instruction with the fp64 oracle); fp64 "
+                          "positions, velocities, energy sums",
             "config": {"workload": f"water-{args.atoms} (rho=0.98 g/cm3), ANI-2x shaped seeded weights, {args.models} model(s), "
                                    f"pair_style ani 5.1 <model> hip {args.models} {args.aev} full single; {what}",
                        "atoms": args.atoms, "models": args.models, "grid": list(comm.grid_for(world)), "nlocal_rank0": nl,
