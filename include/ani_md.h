@@ -35,6 +35,12 @@ int ani_md_forward_ghosts(double* x, const int64_t* owner, const double* shift, 
 /* the pair style's reverse communication on one rank:  f[owner[g]] += f[nlocal + g] */
 int ani_md_reverse_ghosts(double* f, const int64_t* owner, int nlocal, int nghost, void* stream);
 
+/* Several ranks: the two halves of the same exchanges around the all-to-all.
+ * pack:    out[s] = x[owner[s]] + shift[s]   for the nsend atoms this rank sends (its message buffer, [nsend][3])
+ * unpack:  f[owner[s]] += in[s]              for the nsend ghost forces that came back ([nsend][3]) */
+int ani_md_pack_ghosts(const double* x, const int64_t* owner, const double* shift, int nsend, double* out, void* stream);
+int ani_md_unpack_reverse(double* f, const int64_t* owner, int nsend, const double* in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

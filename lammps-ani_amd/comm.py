@@ -199,8 +199,10 @@ class DomainComm:
         dist.all_to_all_single(rc, sc, group=self.group)
         return rc.cpu().tolist()
 
-    def _a2a(self, inp, out_splits, in_splits):
-        out = torch.empty((int(sum(out_splits)),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+    def _a2a(self, inp, out_splits, in_splits, out=None):
+        """out: optional contiguous destination (e.g. the ghost block of the position array: received in place)"""
+        if out is None:
+            out = torch.empty((int(sum(out_splits)),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
         if self.world == 1:
             out.copy_(inp)
         elif self.host_staged:

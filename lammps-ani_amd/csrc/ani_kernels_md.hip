@@ -76,6 +76,22 @@ __global__ __launch_bounds__(256) void forward_ghosts_kernel(double* __restrict_
   x[3 * (size_t)nlocal + t] = x[3 * owner[g] + k] + shift[t];
 }
 
+__global__ __launch_bounds__(256) void pack_ghosts_kernel(const double* __restrict__ x, const long long* __restrict__ owner,
+                                                          const double* __restrict__ shift, int nsend, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * nsend) return;
+  const int g = t / 3, k = t - 3 * g;
+  out[t] = x[3 * owner[g] + k] + shift[t];
+}
+
+__global__ __launch_bounds__(256) void unpack_reverse_kernel(double* __restrict__ f, const long long* __restrict__ owner, int nsend,
+                                                             const double* __restrict__ in) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * nsend) return;
+  const int g = t / 3, k = t - 3 * g;
+  atomicAdd(&f[3 * owner[g] + k], in[t]);   // an atom can be a ghost of several bricks / images
+}
+
 __global__ __launch_bounds__(256) void reverse_ghosts_kernel(double* __restrict__ f, const long long* __restrict__ owner,
                                                              int nlocal, int nghost) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,6 +131,20 @@ int ani_md_reverse_ghosts(double* f, const int64_t* owner, int nlocal, int nghos
   if (nghost <= 0) return 0;
   hipLaunchKernelGGL(reverse_ghosts_kernel, dim3((3 * nghost + 255) / 256), dim3(256), 0, (hipStream_t)stream, f,
                      reinterpret_cast<const long long*>(owner), nlocal, nghost);
+  return (int)hipGetLastError();
+}
+
+int ani_md_pack_ghosts(const double* x, const int64_t* owner, const double* shift, int nsend, double* out, void* stream) {
+  if (nsend <= 0) return 0;
+  hipLaunchKernelGGL(pack_ghosts_kernel, dim3((3 * nsend + 255) / 256), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<const long long*>(owner), shift, nsend, out);
+  return (int)hipGetLastError();
+}
+
+int ani_md_unpack_reverse(double* f, const int64_t* owner, int nsend, const double* in, void* stream) {
+  if (nsend <= 0) return 0;
+  hipLaunchKernelGGL(unpack_reverse_kernel, dim3((3 * nsend + 255) / 256), dim3(256), 0, (hipStream_t)stream, f,
+                     reinterpret_cast<const long long*>(owner), nsend, in);
   return (int)hipGetLastError();
 }
 

@@ -73,6 +73,8 @@ class VerletRun:
             from . import ani_hip
             self._md = ani_hip.lib()
             self._d2max = torch.zeros(1, dtype=torch.float64, device=device)
+            self._sendbuf = torch.empty((0, 3), dtype=torch.float64, device=device)
+            self._recvbuf = torch.empty((0, 3), dtype=torch.float64, device=device)
             ani.set_option("device_overwrite_forces", 1)   # no separate force_clear launch
         self._build_list()
         self._forces()
@@ -145,6 +147,13 @@ class VerletRun:
         if self._fused and self.dc.world == 1:
             self._check(self._md.ani_md_reverse_ghosts(self.f.data_ptr(), self.dc.send_idx.data_ptr(), self.nlocal,
                                                        self.ntotal - self.nlocal, self._stream))
+        elif self._fused:
+            dc, ns = self.dc, int(self.dc.send_idx.numel())
+            if self._recvbuf.shape[0] != ns:
+                self._recvbuf = torch.empty((ns, 3), dtype=torch.float64, device=self.device)
+            dc._a2a(self.f[self.nlocal:], dc.send_splits, dc.recv_splits, out=self._recvbuf)
+            self._check(self._md.ani_md_unpack_reverse(self.f.data_ptr(), dc.send_idx.data_ptr(), ns, self._recvbuf.data_ptr(),
+                                                       self._stream))
         else:
             self.dc.reverse_add(self.f)
 
@@ -225,6 +234,14 @@ class VerletRun:
         elif self._fused and self.dc.world == 1:
             self._check(self._md.ani_md_forward_ghosts(self.x.data_ptr(), self.dc.send_idx.data_ptr(), self.dc.send_shift.data_ptr(),
                                                        self.nlocal, self.ntotal - self.nlocal, self._stream))
+        elif self._fused:
+            # several ranks: one pack kernel, the all-to-all receives straight into the ghost block of x
+            dc, ns = self.dc, int(self.dc.send_idx.numel())
+            if self._sendbuf.shape[0] != ns:
+                self._sendbuf = torch.empty((ns, 3), dtype=torch.float64, device=self.device)
+            self._check(self._md.ani_md_pack_ghosts(self.x.data_ptr(), dc.send_idx.data_ptr(), dc.send_shift.data_ptr(), ns,
+                                                    self._sendbuf.data_ptr(), self._stream))
+            dc._a2a(self._sendbuf, dc.recv_splits, dc.send_splits, out=self.x[self.nlocal:])
         else:
             self.dc.forward_positions(self.x)
         self._forces()
