@@ -113,6 +113,30 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
                             int eflag_atom, int vflag, double* d_f, double* d_ev, double* d_eatom, void* stream);
 
 /*
+ * The same device-resident step in three calls, cut where a domain-decomposed caller exchanges ghost data, so that
+ * both exchanges can run on another stream beside the work that does not need them (the reference has no
+ * counterpart: its forward / reverse communication are LAMMPS' blocking MPI swaps around PairANI::compute,
+ * src/pair_ani.cpp:197-201).  At the first use after a re-neighbouring the library classes the centres: those with a
+ * ghost atom (index >= nlocal) anywhere in their list, and the rest (one host synchronisation per epoch).
+ *   ani_step_begin         needs the positions of the nlocal OWNED atoms only: packs them, screens the neighbour lists
+ *                          and computes the AEVs of the centres without ghosts.
+ *   ani_step_ghosts_ready  call when d_x[nlocal..ntotal) holds this step's ghost positions (stream-ordered after the
+ *                          forward exchange): the centres with ghosts, the MLP of every centre, then the backward pass
+ *                          of the centres with ghosts; when its work is done the GHOST rows of d_f are final (no other
+ *                          centre touches a ghost atom) and the reverse exchange can start.
+ *   ani_step_finish        backward pass of the centres without ghosts; rows [0, nlocal) of d_f, energy, virial, per-atom
+ *                          energies.
+ * Arguments as ani_compute_full_device with ago != 0 (the list of the epoch must be in place: ani_build_list_device or a
+ * call with ago == 0).  The three calls may use different streams if the caller orders them with events; results equal
+ * those of the one-call step up to the order of the fp32 force atomics.  Models or precisions without the fast kernels
+ * (generic AEV shapes, `double`) run the whole step inside ani_step_ghosts_ready.
+ */
+int ani_step_begin(ani_handle* h, int ntotal, int nlocal, const double* d_x, int eflag_atom, int vflag, double* d_f, double* d_ev,
+                   double* d_eatom, void* stream);
+int ani_step_ghosts_ready(ani_handle* h, void* stream);
+int ani_step_finish(ani_handle* h, void* stream);
+
+/*
  * Device-side neighbour list: does on the device what LAMMPS core does on the host for
  * `neighbor <skin> bin` + the full-list request of src/pair_ani.cpp:219-223, and installs the result in the handle
  * as this epoch's list.  After it, call ani_compute_full_device with ago != 0 and NULL list pointers until the next

@@ -21,7 +21,7 @@ HARTREE2KCALMOL = 627.5094738898777
 EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani_use_num_models", "ani_num_species",
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
            "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times",
-           "ani_trace_push", "ani_trace_pop", "ani_trace_mark"]
+           "ani_trace_push", "ani_trace_pop", "ani_trace_mark", "ani_step_begin", "ani_step_ghosts_ready", "ani_step_finish"]
 
 
 class AniError(RuntimeError):
@@ -75,6 +75,10 @@ def lib():
         L.ani_compute_full_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ani_step_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
+        L.ani_step_ghosts_ready.argtypes = [C.c_void_p, C.c_void_p]
+        L.ani_step_finish.argtypes = [C.c_void_p, C.c_void_p]
         L.ani_build_list_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
                                             C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
         L.ani_build_list.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
@@ -160,6 +164,18 @@ class ANI:
         rc = self._lib.ani_compute_full_device(self._h, ntotal, nlocal, d_species, d_x, npairs, d_ilist, d_jlist,
                                                d_numneigh, ago, int(eflag_atom), int(vflag), d_f, d_ev, d_eatom, stream)
         self._check(rc)
+
+    def step_begin(self, ntotal, nlocal, d_x, d_f, d_ev, d_eatom=None, eflag_atom=False, vflag=False, stream=None):
+        """Split device-resident step, part 1 of 3 (include/ani_hip.h): needs the owned atoms' positions only."""
+        self._check(self._lib.ani_step_begin(self._h, ntotal, nlocal, d_x, int(eflag_atom), int(vflag), d_f, d_ev, d_eatom, stream))
+
+    def step_ghosts_ready(self, stream=None):
+        """Part 2: the ghost positions are in place; afterwards the ghost rows of the force array are final."""
+        self._check(self._lib.ani_step_ghosts_ready(self._h, stream))
+
+    def step_finish(self, stream=None):
+        """Part 3: forces of the owned atoms, energy, virial."""
+        self._check(self._lib.ani_step_finish(self._h, stream))
 
     def build_list_device(self, ntotal, nlocal, d_species, d_x, cutneigh, lo, hi, stream=None) -> int:
         """Device-side full neighbour list (ani_build_list_device); returns the pair count.  Follow with

@@ -106,6 +106,12 @@ struct ani_handle {
 
   // list epoch state (valid while ago > 0)
   bool have_list = false;
+  // split step (ani_step_*): rows with a ghost among their candidates first in row_list, the others after
+  DevBuf<int> row_flag, row_list, row_count;
+  int n_boundary = 0;
+  bool classes_valid = false;
+  int split_phase = 0;          // 0: no split step open, 1: begun, 2: ghosts done
+  struct { const double* d_x; int eflag_atom, vflag; double *d_f, *d_ev, *d_eatom; } split{};
   int nlocal = 0, ntotal = 0, nrows = 0;
   long long npairs = 0;
   int count[kMaxSpecies] = {0}, row_start[kMaxSpecies] = {0};
@@ -365,6 +371,8 @@ int rebuild(ani_handle* h, hipStream_t st) {
   roctxMarkA("neighbor list rebuilt");   // src/ani_csrc/ani.cpp:128,215
   TraceRange tr("ani: list epoch set-up (offsets, species buckets, segment sort)");
   h->need_origin = true;
+  h->classes_valid = false;
+  h->split_phase = 0;
   const int nlocal = h->nlocal;
   const int nrows_cap = round_up(nlocal, kRowTile) + m.S * kRowTile;
   HIP_TRY(h, h->nbr_off.reserve((size_t)nlocal + 1));
@@ -668,15 +676,21 @@ int run_step64(ani_handle* h, const double* d_x, int eflag_atom, int vflag, doub
 }
 
 // the per-step pipeline on device-resident inputs; the list of this epoch is already in the handle's buffers
-int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double* d_f, int f_accumulate, double* d_ev,
-             double* d_eatom, hipStream_t st) {
-  if (!h->use_single) return run_step64(h, d_x, eflag_atom, vflag, d_f, f_accumulate, d_ev, d_eatom, st);
-  const HostModel& m = h->model;
+// ---- one step of the fp32 pipeline, in pieces: a whole step (run_step) strings them together on one stream; the split
+// entry points (ani_step_begin / ani_step_ghosts_ready / ani_step_finish) cut it where the ghost exchange happens ----
+struct StepCtx {
+  const double* d_x = nullptr;
+  int eflag_atom = 0, vflag = 0, f_accumulate = 0;
+  double *d_f = nullptr, *d_ev = nullptr, *d_eatom = nullptr;
+};
+
+int step_prologue(ani_handle* h, const StepCtx& c, bool timed, hipStream_t st) {
   HIP_TRY(h, h->xyzs.reserve(h->ntotal));
   HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 4));  // one float4 per atom
   HIP_TRY(h, h->virial_acc.reserve(9 * kVirialSlots));
   HIP_TRY(h, h->err_flag.reserve(1, true));
-  if (h->timing) {
+  h->evt = nullptr;
+  if (timed && h->timing) {
     if (h->evt_used + 6 > h->evt_pool.size()) {
       const size_t old = h->evt_pool.size();
       h->evt_pool.resize(old + 6 * 64, nullptr);
@@ -685,47 +699,60 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
     h->evt = &h->evt_pool[h->evt_used];
     h->evt_used += 6;
   }
-
-  TraceRange tr_step("ani: step");
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[0], st));
+  if (h->evt) HIP_TRY(h, hipEventRecord(h->evt[0], st));
   HIP_TRY(h, h->origin.reserve(3));
   if (h->need_origin) {
-    launch_origin(d_x, h->ntotal, h->origin.p, st);
+    launch_origin(c.d_x, h->ntotal, h->origin.p, st);
     h->need_origin = false;
   }
-  launch_pack(d_x, h->species.p, h->ntotal, h->cmap, h->xyzs.p, h->fbuf.p, h->virial_acc.p, d_ev, h->origin.p, st);  // also clears fbuf / virial_acc
+  if (h->model.has_rep) {
+    HIP_TRY(h, h->erep.reserve(kVirialSlots));
+    HIP_TRY(h, hipMemsetAsync(h->erep.p, 0, sizeof(double) * kVirialSlots, st));
+  }
+  return ANI_OK;
+}
 
+// atoms [i0, i1) -> fp32 positions, force accumulators cleared; `first`: also the step's virial / energy accumulators
+void step_pack(ani_handle* h, const StepCtx& c, int i0, int i1, bool first, hipStream_t st) {
+  launch_pack(c.d_x, h->species.p, i0, i1, h->cmap, h->xyzs.p, h->fbuf.p, first ? h->virial_acc.p : nullptr,
+              first ? c.d_ev : nullptr, h->origin.p, st);
+}
+
+// rows: 0 = every row, 1 = the rows with a ghost among their candidates, 2 = the others (fast path only)
+AevArgs step_aev_args(ani_handle* h, const StepCtx& c, int rows) {
   AevArgs a{};
   a.xyzs = h->xyzs.p; a.ilist = h->ilist.p; a.numneigh = h->numneigh.p; a.nbr_off = h->nbr_off.p; a.jlist = h->jlist.p;
   a.centre_of_row = h->centre_of_row.p; a.row_info = h->row_info.p; a.nrows = h->nrows; a.aev = h->aev.p; a.gaev = h->gaev.p; a.fbuf = h->fbuf.p;
-  a.virial = vflag ? h->virial_acc.p : nullptr;
+  a.virial = c.vflag ? h->virial_acc.p : nullptr;
   a.err_flag = h->err_flag.p;
   a.cl_hdr = h->cl_hdr.p; a.cl_xyz = h->cl_xyz.p; a.cl_j = h->cl_j.p; a.cl_stride = h->cl_stride;
+  a.row_list = nullptr; a.k0 = 0; a.kcount = h->nrows;
+  if (rows == 1) { a.row_list = h->row_list.p; a.k0 = 0; a.kcount = h->n_boundary; }
+  if (rows == 2) { a.row_list = h->row_list.p; a.k0 = h->n_boundary; a.kcount = h->nrows - h->n_boundary; }
+  return a;
+}
+
+int step_compact_forward(ani_handle* h, const AevArgs& a, hipStream_t st) {
   {
     TraceRange tr("ani: neighbour compaction");
     launch_nbr_compact(h->ap_run, a, h->max_numneigh, st);
   }
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[5], st));
+  if (h->evt) HIP_TRY(h, hipEventRecord(h->evt[5], st));
   {
     TraceRange tr("ani: AEV forward");
     launch_aev_forward(h->ap_run, a, h->max_numneigh, st);
   }
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[1], st));
-  {
-    TraceRange tr("ani: MLP forward + backward");
-    const int rcm = compute_mlp(h, st);
-    if (rcm) return rcm;
-  }
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[2], st));
-  if (m.has_rep) {
-    HIP_TRY(h, h->erep.reserve(kVirialSlots));
-    HIP_TRY(h, hipMemsetAsync(h->erep.p, 0, sizeof(double) * kVirialSlots, st));
-  }
+  if (h->evt) HIP_TRY(h, hipEventRecord(h->evt[1], st));
+  return ANI_OK;
+}
+
+int step_backward(ani_handle* h, const StepCtx& c, const AevArgs& a, hipStream_t st) {
+  const HostModel& m = h->model;
   // the fast backward kernel applies the repulsion in its radial stage (tables by compact species, like the AEV layout);
   // the generic kernel does not, and then the stand-alone kernel adds it
   RepTab rt{};
   if (m.has_rep && h->ap_run.S <= 8) {
-    rt.on = 1; rt.cutoff = (float)m.rep_cut; rt.erep = h->erep.p; rt.x64 = d_x;
+    rt.on = 1; rt.cutoff = (float)m.rep_cut; rt.erep = h->erep.p; rt.x64 = c.d_x;
     std::vector<int> act;
     for (int s = 0; s < m.S; s++) if (h->active_mask & (1 << s)) act.push_back(s);
     if ((int)act.size() != h->ap_run.S) { act.clear(); for (int s = 0; s < m.S; s++) act.push_back(s); }
@@ -738,34 +765,77 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
         rt.k[8 * ca + cb] = (float)m.rep_tables[2 * n2 + src];
       }
   }
-  TraceRange tr_bwd("ani: AEV backward + finish");
   const bool rep_done = launch_aev_backward(h->ap_run, a, h->max_numneigh, st, rt.on ? &rt : nullptr) && rt.on;
   if (m.has_rep && !rep_done) {
     RepArgs ra{};
     ra.row_info = h->row_info.p; ra.nrows = h->nrows; ra.jlist = h->jlist.p; ra.species = h->species.p;
-    ra.pos = d_x; ra.fbuf = h->fbuf.p; ra.virial = vflag ? h->virial_acc.p : nullptr; ra.erep = h->erep.p;
+    ra.pos = c.d_x; ra.fbuf = h->fbuf.p; ra.virial = c.vflag ? h->virial_acc.p : nullptr; ra.erep = h->erep.p;
     ra.tables = h->rep_tables.p; ra.S = m.S; ra.nslots = kVirialSlots; ra.vslots = kVirialSlots; ra.cutoff = m.rep_cut;
     launch_repulsion(ra, false, st);
   }
-  if (h->timing) HIP_TRY(h, hipEventRecord(h->evt[3], st));
+  return ANI_OK;
+}
 
+// forces of the atoms [atom0, atom1) leave the accumulators; `energy`: also the step's energy / virial / repulsion energy
+void step_finish(ani_handle* h, const StepCtx& c, int atom0, int atom1, bool energy, hipStream_t st) {
+  const HostModel& m = h->model;
   FinishArgs fa{};
   fa.e_rows = h->e_rows.p; fa.M = m.M; fa.nrows = h->nrows; fa.nrows_ld = h->nrows;
   fa.centre_of_row = h->centre_of_row.p; fa.ilist = h->ilist.p; fa.species = h->species.p;
   for (int s = 0; s < m.S; s++) fa.sae[s] = m.sae[s];
-  fa.fbuf = h->fbuf.p; fa.ntotal = h->ntotal;
-  fa.virial_acc = vflag ? h->virial_acc.p : nullptr;
-  fa.f_out = d_f; fa.f_accumulate = f_accumulate; fa.ev_out = d_ev;
-  fa.eatom_out = eflag_atom ? d_eatom : nullptr;
+  fa.fbuf = h->fbuf.p; fa.atom0 = atom0; fa.atom1 = atom1; fa.energy = energy ? 1 : 0;
+  fa.virial_acc = c.vflag ? h->virial_acc.p : nullptr;
+  fa.f_out = c.d_f; fa.f_accumulate = c.f_accumulate; fa.ev_out = c.d_ev;
+  fa.eatom_out = c.eflag_atom ? c.d_eatom : nullptr;
   fa.err_flag = h->err_flag.p;
   launch_finish(fa, st);
-  if (m.has_rep) launch_repulsion_energy(h->erep.p, kVirialSlots, d_ev, st);
-  if (h->timing) {
-    HIP_TRY(h, hipEventRecord(h->evt[4], st));
+  if (energy && m.has_rep) launch_repulsion_energy(h->erep.p, kVirialSlots, c.d_ev, st);
+}
+
+int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double* d_f, int f_accumulate, double* d_ev,
+             double* d_eatom, hipStream_t st) {
+  if (!h->use_single) return run_step64(h, d_x, eflag_atom, vflag, d_f, f_accumulate, d_ev, d_eatom, st);
+  StepCtx c;
+  c.d_x = d_x; c.eflag_atom = eflag_atom; c.vflag = vflag; c.f_accumulate = f_accumulate; c.d_f = d_f; c.d_ev = d_ev; c.d_eatom = d_eatom;
+  TraceRange tr_step("ani: step");
+  int rc = step_prologue(h, c, true, st);
+  if (rc) return rc;
+  step_pack(h, c, 0, h->ntotal, true, st);   // also clears fbuf / virial_acc / the energy word
+  const AevArgs a = step_aev_args(h, c, 0);
+  rc = step_compact_forward(h, a, st);
+  if (rc) return rc;
+  {
+    TraceRange tr("ani: MLP forward + backward");
+    rc = compute_mlp(h, st);
+    if (rc) return rc;
   }
+  if (h->evt) HIP_TRY(h, hipEventRecord(h->evt[2], st));
+  TraceRange tr_bwd("ani: AEV backward + finish");
+  rc = step_backward(h, c, a, st);
+  if (rc) return rc;
+  if (h->evt) HIP_TRY(h, hipEventRecord(h->evt[3], st));
+  step_finish(h, c, 0, h->ntotal, true, st);
+  if (h->evt) HIP_TRY(h, hipEventRecord(h->evt[4], st));
   HIP_TRY(h, hipGetLastError());
   return ANI_OK;
 }
+
+// Split step (include/ani_hip.h, ani_step_*).  The rows are classed once per list epoch, on first use.
+int ensure_row_classes(ani_handle* h, hipStream_t st) {
+  if (h->classes_valid) return ANI_OK;
+  HIP_TRY(h, h->row_flag.reserve(std::max(h->nrows, 1)));
+  HIP_TRY(h, h->row_list.reserve(std::max(h->nrows, 1)));
+  HIP_TRY(h, h->row_count.reserve(1));
+  launch_row_classes(h->row_info.p, h->jlist.p, h->nrows, h->nlocal, h->row_flag.p, h->row_list.p, h->row_count.p, st);
+  int nb = 0;
+  HIP_TRY(h, hipMemcpyAsync(&nb, h->row_count.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));   // once per re-neighbouring
+  h->n_boundary = nb;
+  h->classes_valid = true;
+  return ANI_OK;
+}
+
+bool split_supported(const ani_handle* h) { return h->use_single && h->cl_stride > 0 && !(h->model.has_rep && h->ap_run.S > 8); }
 
 int check_args(ani_handle* h, int ntotal, int nlocal, long long npairs, int ago) {
   if (!h) return ANI_ERR_ARG;
@@ -862,7 +932,7 @@ void ani_destroy(ani_handle* h) {
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
   h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
-  h->xyzs.release(); h->cl_xyz.release(); h->cl_hdr.release(); h->cl_j.release(); h->row_info.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->origin.release();
+  h->xyzs.release(); h->cl_xyz.release(); h->cl_hdr.release(); h->cl_j.release(); h->row_info.release(); h->row_flag.release(); h->row_list.release(); h->row_count.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->origin.release();
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();
@@ -909,6 +979,79 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
   // LAMMPS_ANI_PROFILING (src/pair_ani_kokkos.cpp:68-70,210-212): the host's timers see the device work of this call
   if (rc == ANI_OK && h->profiling) HIP_TRY(h, hipStreamSynchronize(st));
   return rc;
+}
+
+// ---- split step: see include/ani_hip.h ----------------------------------------------------------------------
+static StepCtx split_ctx(const ani_handle* h) {
+  StepCtx c;
+  c.d_x = h->split.d_x; c.eflag_atom = h->split.eflag_atom; c.vflag = h->split.vflag; c.f_accumulate = h->dev_overwrite ? 0 : 1;
+  c.d_f = h->split.d_f; c.d_ev = h->split.d_ev; c.d_eatom = h->split.d_eatom;
+  return c;
+}
+
+int ani_step_begin(ani_handle* h, int ntotal, int nlocal, const double* d_x, int eflag_atom, int vflag, double* d_f, double* d_ev,
+                   double* d_eatom, void* stream) {
+  int rc = check_args(h, ntotal, nlocal, 0, /*ago=*/1);
+  if (rc) return rc;
+  if (!d_x || !d_ev) { h->err = "null device pointer"; return ANI_ERR_ARG; }
+  if (h->split_phase != 0) { h->err = "ani_step_begin: the previous split step was not finished"; return ANI_ERR_ARG; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  h->split.d_x = d_x; h->split.eflag_atom = eflag_atom; h->split.vflag = vflag; h->split.d_f = d_f; h->split.d_ev = d_ev; h->split.d_eatom = d_eatom;
+  h->split_phase = 1;
+  if (!split_supported(h)) return ANI_OK;   // the whole step runs in ani_step_ghosts_ready
+  rc = ensure_row_classes(h, st);
+  if (rc) { h->split_phase = 0; return rc; }
+  const StepCtx c = split_ctx(h);
+  TraceRange tr("ani: step, rows without ghosts: pack + compaction + AEV forward");
+  rc = step_prologue(h, c, false, st);
+  if (rc) { h->split_phase = 0; return rc; }
+  step_pack(h, c, 0, h->nlocal, true, st);
+  rc = step_compact_forward(h, step_aev_args(h, c, 2), st);
+  if (rc) { h->split_phase = 0; return rc; }
+  HIP_TRY(h, hipGetLastError());
+  return ANI_OK;
+}
+
+int ani_step_ghosts_ready(ani_handle* h, void* stream) {
+  if (!h) return ANI_ERR_ARG;
+  if (h->split_phase != 1) { h->err = "ani_step_ghosts_ready without ani_step_begin"; return ANI_ERR_ARG; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const StepCtx c = split_ctx(h);
+  h->split_phase = 2;
+  if (!split_supported(h)) {
+    const int rc = run_step(h, c.d_x, c.eflag_atom, c.vflag, c.d_f, c.f_accumulate, c.d_ev, c.d_eatom, st);
+    if (rc) h->split_phase = 0;
+    return rc;
+  }
+  TraceRange tr("ani: step, rows with ghosts + MLP + their backward pass");
+  step_pack(h, c, h->nlocal, h->ntotal, false, st);
+  const AevArgs a = step_aev_args(h, c, 1);
+  int rc = step_compact_forward(h, a, st);
+  if (!rc) rc = compute_mlp(h, st);
+  if (!rc) rc = step_backward(h, c, a, st);
+  if (rc) { h->split_phase = 0; return rc; }
+  step_finish(h, c, h->nlocal, h->ntotal, false, st);   // the ghost atoms' forces are complete: no other row touches them
+  HIP_TRY(h, hipGetLastError());
+  return ANI_OK;
+}
+
+int ani_step_finish(ani_handle* h, void* stream) {
+  if (!h) return ANI_ERR_ARG;
+  if (h->split_phase != 2) { h->err = "ani_step_finish without ani_step_ghosts_ready"; return ANI_ERR_ARG; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  h->split_phase = 0;
+  if (!split_supported(h)) return ANI_OK;
+  const StepCtx c = split_ctx(h);
+  TraceRange tr("ani: step, backward pass of the rows without ghosts + finish");
+  const int rc = step_backward(h, c, step_aev_args(h, c, 2), st);
+  if (rc) return rc;
+  step_finish(h, c, 0, h->nlocal, true, st);
+  HIP_TRY(h, hipGetLastError());
+  if (h->profiling) HIP_TRY(h, hipStreamSynchronize(st));
+  return ANI_OK;
 }
 
 void ani_trace_push(const char* name) { if (name) roctxRangePushA(name); }

@@ -85,8 +85,12 @@ struct SpeciesMap { int m[kMaxSpecies]; };
 // energy/virial output the finish kernel adds to; may be NULL) -- no separate memsets
 // positions are stored relative to d_origin[3] (device; launch_origin sets it to the midpoint of the atoms' bounding box)
 void launch_origin(const double* d_x, int ntotal, double* d_origin, hipStream_t st);
-void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
+// atoms [i0, i1); virial_acc / ev_zero may be NULL (a second launch of a step for the ghost atoms clears neither)
+void launch_pack(const double* d_x, const int* d_species, int i0, int i1, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
                  double* virial_acc, double* ev_zero, const double* d_origin, hipStream_t st);
+// rebuild time: list[0 .. count[0]) = the rows with a ghost atom (index >= nlocal) among their candidates, ascending; then
+// the other rows, ascending.  flag: scratch, [nrows]
+void launch_row_classes(const int4* row_info, const int* jlist, int nrows, int nlocal, int* flag, int* list, int* count, hipStream_t st);
 
 // rebuild-time preparation: neighbour offsets, species buckets.  All outputs device arrays.
 struct PrepOut {
@@ -120,6 +124,10 @@ struct AevArgs {
   float4* cl_xyz;    // [nrows*cl_stride] {dx, dy, dz, r}: kMaxAng slots for the neighbours inside Rca, then the radial-only ones
   int* cl_j;         // [nrows*cl_stride] neighbour atom index
   int cl_stride;     // entries reserved per row (kMaxAng + the kernels' radial LDS capacity)
+  // the range of rows a fast-path launch walks: row_list[k0 + k], k in [0, kcount); without a list the rows k0 + k
+  // (every row: k0 = 0, kcount = nrows).  The generic kernels always take every row.
+  const int* row_list;
+  int k0, kcount;
 };
 // entries per row the compact lists need (0: the model shape takes the generic kernels, which keep no lists)
 int aev_compact_stride(const AevParams& p, int max_numneigh);
@@ -192,7 +200,8 @@ struct FinishArgs {
   const int* species;    // [ntotal]
   double sae[kMaxSpecies];
   const float* fbuf;     // [ntotal*4] {fx,fy,fz,-}
-  int ntotal;
+  int atom0, atom1;      // forces of the atoms [atom0, atom1) are written
+  int energy;            // 1: also reduce energy (+ virial); 0: forces only (the ghost atoms' part of a split step)
   const double* virial_acc;  // [kVirialSlots][9] Hartree (unsymmetrised partial sums), or NULL
   double* f_out;         // [ntotal*3] kcal/mol/A
   int f_accumulate;      // 1: +=, 0: overwrite

@@ -236,8 +236,15 @@ __device__ __forceinline__ int4 uniform4(const int4& v) {
   return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
                    __builtin_amdgcn_readfirstlane(v.w));
 }
-__device__ __forceinline__ int4 load_info(const AevArgs& a, int row) {   // per-lane copy; rows past the end read the last row
-  return a.row_info[opaque(row < a.nrows ? row : a.nrows - 1)];
+// The fast kernels walk the k-th row of a range, k in [0, a.kcount): row = a.row_list[a.k0 + k], or a.k0 + k without a
+// list (every row: k0 = 0, kcount = nrows).  Lists: the rows with / without a ghost atom among their candidates, so
+// that a step can be cut where the ghost exchange has to happen (ani_step_* in ani_hip.h).
+__device__ __forceinline__ int4 load_info(const AevArgs& a, int k) {   // per-lane copy; k past the end reads the last row
+  const int kk = opaque(k < a.kcount ? k : a.kcount - 1);
+  const int r = a.row_list ? a.row_list[a.k0 + kk] : a.k0 + kk;
+  int4 info = a.row_info[r];
+  info.w = r;   // the row travels with its stage (the centre's position in ilist, which sat here, is not used below)
+  return info;
 }
 template <int NCH>
 __device__ __forceinline__ void load_j(const AevArgs& a, const int4 info, int lane, int (&jj)[NCH]) {
@@ -259,24 +266,25 @@ template <int NCH>
 __global__ __launch_bounds__(64 * kWavesC, NCH >= 4 ? 4 : 5) void nbr_compact_kernel(AevParams p, AevArgs a, int cap) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int nw = gridDim.x * kWavesC;
-  int row = blockIdx.x * kWavesC + wave;
-  if (row >= a.nrows) return;
+  int k = blockIdx.x * kWavesC + wave;
+  if (k >= a.kcount) return;
   const int cap2 = a.cl_stride - kMaxAng;   // room of the radial-only stream
-  int4 info = load_info(a, row), info1 = load_info(a, row + nw), info2 = load_info(a, row + 2 * nw);
+  int4 info = load_info(a, k), info1 = load_info(a, k + nw), info2 = load_info(a, k + 2 * nw);
   int jj[NCH], jj1[NCH];
   float4 xi, xx[NCH];
   load_j(a, info, lane, jj);
   load_j(a, info1, lane, jj1);
   gather_x(a, info, jj, xi, xx);
-  while (row < a.nrows) {
+  while (k < a.kcount) {
     // next stages
     float4 xi1, xx1[NCH];
     gather_x(a, info1, jj1, xi1, xx1);
     int jj2[NCH];
     load_j(a, info2, lane, jj2);
-    const int4 info3 = load_info(a, row + 3 * nw);
+    const int4 info3 = load_info(a, k + 3 * nw);
 
     const int4 inf = uniform4(info);
+    const int row = inf.w;
     int4* hdr = a.cl_hdr + 2 * (size_t)row;
     const int i = inf.x, beg = inf.y, n = inf.x < 0 ? 0 : inf.z;
     float4* oxyz = a.cl_xyz + (size_t)row * a.cl_stride;
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(64 * kWavesC, NCH >= 4 ? 4 : 5) void nbr_compact_ke
     xi = xi1;
 #pragma unroll
     for (int c = 0; c < NCH; c++) { jj[c] = jj1[c]; xx[c] = xx1[c]; jj1[c] = jj2[c]; }
-    row += nw;
+    k += nw;
   }
 }
 
@@ -777,7 +785,8 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
 // 22 registers that the pair loop uses better.
 #define ANI_PERSISTENT_LOOP(KW, NCH, BWD, GR, CENTRE)                                                      \
   const int nw = gridDim.x * KW;                                                                          \
-  for (int row = blockIdx.x * KW + wave; row < a.nrows; row += nw) {                                      \
+  for (int k = blockIdx.x * KW + wave; k < a.kcount; k += nw) {                                           \
+    const int row = a.row_list ? __builtin_amdgcn_readfirstlane(a.row_list[a.k0 + k]) : a.k0 + k;         \
     const hdr_t hc = load_header(a, row);                                                                 \
     if (hc[0] < 0) continue;                                                                              \
     Loaded<NCH, BWD, GR> cur;                                                                             \
@@ -1440,7 +1449,7 @@ static void launch_fast(K kernel, const AevParams& p, const AevArgs& a, int wave
                         Extra... extra) {
   // raising the dynamic-LDS limit is per kernel; every instantiation passes through here once
   (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.nrows, waves, lds)), dim3(64 * waves), lds, st, p, a, cap, rowf,
+  hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.kcount, waves, lds)), dim3(64 * waves), lds, st, p, a, cap, rowf,
                      extra...);
 }
 
@@ -1449,10 +1458,10 @@ int aev_compact_stride(const AevParams& p, int max_numneigh) {
 }
 
 void launch_nbr_compact(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
-  if (a.nrows <= 0 || !aev_fast_path(p, max_numneigh)) return;
+  if (a.kcount <= 0 || !aev_fast_path(p, max_numneigh)) return;
   const int cap = radial_cap(p, max_numneigh);
   auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.nrows, kWavesC, 0)), dim3(64 * kWavesC), 0, st, p, a, cap);
+    hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.kcount, kWavesC, 0)), dim3(64 * kWavesC), 0, st, p, a, cap);
   };
   if (max_numneigh <= 128) go(nbr_compact_kernel<2>);
   else if (max_numneigh <= 192) go(nbr_compact_kernel<3>);
@@ -1463,6 +1472,7 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
   if (a.nrows <= 0) return;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
   if (aev_fast_path(p, max_numneigh)) {
+    if (a.kcount <= 0) return;   // an empty range of rows
     const int cap = radial_cap(p, max_numneigh);
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, false, rowf) * 4 * kWaves;
@@ -1484,6 +1494,7 @@ bool launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
   if (rep) rt = *rep;
   const dim3 grid((a.nrows + kWaves - 1) / kWaves), block(64 * kWaves);
   if (aev_fast_path(p, max_numneigh)) {
+    if (a.kcount <= 0) return true;
     const int cap = radial_cap(p, max_numneigh);
     const int rowf = (p.aev_stride + 63) / 64 * 64;
     const size_t lds = (size_t)fast_wave_floats_row(cap, true, rowf) * 4 * kWavesB;

@@ -44,13 +44,14 @@ void launch_origin(const double* d_x, int ntotal, double* d_origin, hipStream_t 
   hipLaunchKernelGGL(origin_kernel, dim3(1), dim3(1024), 0, st, d_x, ntotal, d_origin);
 }
 
-__global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int ntotal, SpeciesMap cmap,
+__global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int i0, int i1, SpeciesMap cmap,
                             float4* __restrict__ out, float* __restrict__ fbuf, double* __restrict__ virial_acc,
                             double* __restrict__ ev_zero, const double* __restrict__ origin) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 9 * kVirialSlots) virial_acc[i] = 0.0;
-  if (ev_zero && i < 10) ev_zero[i] = 0.0;   // the finish kernel ADDS its block sums of the energy
-  if (i >= ntotal) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (virial_acc && t < 9 * kVirialSlots) virial_acc[t] = 0.0;
+  if (ev_zero && t < 10) ev_zero[t] = 0.0;   // the finish kernel ADDS its block sums of the energy
+  const int i = i0 + t;
+  if (i >= i1) return;
   // coordinates.to(dtype): src/ani_csrc/ani.cpp:206-207, relative to the epoch's origin.  The species stored next to the
   // position is the index the AEV kernels use (compact index among the species present, see ani_hip.cpp:specialize).
   const int sp = species[i];
@@ -60,10 +61,13 @@ __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict_
   reinterpret_cast<float4*>(fbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-void launch_pack(const double* d_x, const int* d_species, int ntotal, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
+void launch_pack(const double* d_x, const int* d_species, int i0, int i1, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
                  double* virial_acc, double* ev_zero, const double* d_origin, hipStream_t st) {
-  const int nthr = ntotal > 9 * kVirialSlots ? ntotal : 9 * kVirialSlots;
-  hipLaunchKernelGGL(pack_kernel, dim3((nthr + 255) / 256), dim3(256), 0, st, d_x, d_species, ntotal, cmap,
+  int nthr = i1 - i0;
+  if (virial_acc && nthr < 9 * kVirialSlots) nthr = 9 * kVirialSlots;
+  if (ev_zero && nthr < 10) nthr = 10;
+  if (nthr <= 0) return;
+  hipLaunchKernelGGL(pack_kernel, dim3((nthr + 255) / 256), dim3(256), 0, st, d_x, d_species, i0, i1, cmap,
                      xyzs, fbuf, virial_acc, ev_zero, d_origin);
 }
 
@@ -203,7 +207,7 @@ constexpr int kFinishBlocks = 128;
 
 __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
   __shared__ double red[256];
-  const int b = blockIdx.x;
+  const int b = a.energy ? blockIdx.x : blockIdx.x + kFinishBlocks + 1;   // without the energy / virial blocks
   if (b < kFinishBlocks) {
     double acc = 0.0;
     for (int row = b * blockDim.x + threadIdx.x; row < a.nrows; row += kFinishBlocks * blockDim.x) {
@@ -251,15 +255,76 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
     }
     return;
   }
-  const int i = (b - kFinishBlocks - 1) * blockDim.x + threadIdx.x;
-  if (i >= 3 * a.ntotal) return;
+  const int i = 3 * a.atom0 + (b - kFinishBlocks - 1) * blockDim.x + threadIdx.x;
+  if (i >= 3 * a.atom1) return;
   const double v = (double)a.fbuf[4 * (i / 3) + (i % 3)] * 627.5094738898777;  // accumulators are one float4 per atom
   a.f_out[i] = a.f_accumulate ? a.f_out[i] + v : v;
 }
 
 void launch_finish(const FinishArgs& a, hipStream_t st) {
-  const int n3 = a.f_out ? a.ntotal * 3 : 0;
-  hipLaunchKernelGGL(finish_kernel, dim3(kFinishBlocks + 1 + (n3 + 255) / 256), dim3(256), 0, st, a);
+  const int n3 = a.f_out ? (a.atom1 - a.atom0) * 3 : 0;
+  const int blocks = (a.energy ? kFinishBlocks + 1 : 0) + (n3 + 255) / 256;
+  if (blocks <= 0) return;
+  hipLaunchKernelGGL(finish_kernel, dim3(blocks), dim3(256), 0, st, a);
+}
+
+// ---- rows with and without a ghost atom among their candidates (rebuild time) ---------------------------------
+// flag[row] = 1 if any entry of the row's list is a ghost (index >= nlocal); one wave per row
+__global__ __launch_bounds__(256) void classify_rows_kernel(const int4* __restrict__ row_info, const int* __restrict__ jlist, int nrows,
+                                                            int nlocal, int* __restrict__ flag) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  const int4 info = row_info[row];
+  bool ghost = false;
+  if (info.x >= 0)
+    for (int q = lane; q < info.z; q += 64) ghost = ghost || jlist[info.y + q] >= nlocal;
+  const bool any = __ballot(ghost) != 0ULL;
+  if (lane == 0) flag[row] = any ? 1 : 0;
+}
+
+// stable partition by one workgroup: list = the flagged rows in ascending order, then the others; count[0] = flagged
+__global__ __launch_bounds__(1024) void partition_rows_kernel(const int* __restrict__ flag, int nrows, int* __restrict__ list,
+                                                              int* __restrict__ count) {
+  __shared__ int wsum[16], tot;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto block_scan = [&](bool f, int& before, int& total) {   // exclusive rank of this thread's flag inside the block
+    const unsigned long long m = __ballot(f);
+    const int inw = __popcll(m & ((1ULL << lane) - 1ULL));
+    __syncthreads();
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0, t = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) base += wsum[w]; t += wsum[w]; }
+    before = base + inw;
+    total = t;
+  };
+  int nb = 0;
+  for (int r0 = 0; r0 < nrows; r0 += 1024) {
+    const int r = r0 + threadIdx.x;
+    int before, total;
+    block_scan(r < nrows && flag[r] != 0, before, total);
+    nb += total;
+  }
+  if (threadIdx.x == 0) { tot = nb; count[0] = nb; }
+  __syncthreads();
+  nb = tot;
+  int doneB = 0, doneI = 0;
+  for (int r0 = 0; r0 < nrows; r0 += 1024) {
+    const int r = r0 + threadIdx.x;
+    const bool in = r < nrows, f = in && flag[r] != 0;
+    int before, total;
+    block_scan(f, before, total);
+    if (f) list[doneB + before] = r;
+    else if (in) list[nb + doneI + (threadIdx.x - before)] = r;
+    doneB += total;
+    doneI += min(1024, nrows - r0) - total;
+  }
+}
+
+void launch_row_classes(const int4* row_info, const int* jlist, int nrows, int nlocal, int* flag, int* list, int* count, hipStream_t st) {
+  if (nrows <= 0) { (void)hipMemsetAsync(count, 0, sizeof(int), st); return; }
+  hipLaunchKernelGGL(classify_rows_kernel, dim3((nrows + 3) / 4), dim3(256), 0, st, row_info, jlist, nrows, nlocal, flag);
+  hipLaunchKernelGGL(partition_rows_kernel, dim3(1), dim3(1024), 0, st, flag, nrows, list, count);
 }
 
 }  // namespace ani

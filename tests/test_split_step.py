@@ -1,0 +1,84 @@
+"""GPU: the device-resident step in three calls (include/ani_hip.h, ani_step_begin / ani_step_ghosts_ready /
+ani_step_finish) gives what the one-call step gives.  The cut is where a domain-decomposed caller exchanges ghost data:
+part 1 may only look at owned atoms (their ghost positions are poisoned here until part 2), and after part 2 the ghost
+rows of the force array must already be final (they are copied out before part 3 runs)."""
+import numpy as np
+import pytest
+import torch
+
+from lammps_ani_amd import harness as hx
+
+pytestmark = pytest.mark.gpu
+
+F_TOL = 2.3e-3
+
+
+def _device_inputs(inp, dev):
+    return dict(x=torch.from_numpy(inp.x.reshape(-1).copy()).to(dev), species=torch.from_numpy(inp.species.astype(np.int32)).to(dev),
+                ilist=torch.from_numpy(inp.ilist).to(dev), numneigh=torch.from_numpy(inp.numneigh).to(dev),
+                jlist=torch.from_numpy(inp.jlist).to(dev))
+
+
+@pytest.mark.parametrize("case", ["water_m1", "water_m8_virial", "mixed_rep", "pyaev", "double", "two_bricks"])
+def test_split_step_equals_one_call_step(case, model_cache):
+    from lammps_ani_amd import ani_hip
+    dev = torch.device("cuda:0")
+    kw = dict(use_cuaev=True, use_single=True)
+    vflag = eatom = False
+    grid, rank = (1, 1, 1), 0
+    if case == "water_m1":
+        p, sysm = model_cache("ani2x", 1, 2024), hx.spatial_sort(hx.water_box(9000, seed=3))
+    elif case == "water_m8_virial":
+        p, sysm, vflag, eatom = model_cache("ani2x", 8, 2024), hx.spatial_sort(hx.water_box(3000, seed=4)), True, True
+    elif case == "mixed_rep":
+        p, sysm = model_cache("ani1x", 2, 2024, repulsion=True), hx.random_box(1500, 4, 28.0, seed=6)
+    elif case == "pyaev":
+        p, sysm, kw = model_cache("ani2x", 1, 2024), hx.water_box(1500, seed=5), dict(use_cuaev=False, use_single=True)
+    elif case == "double":
+        p, sysm, kw = model_cache("ani2x", 1, 2024), hx.water_box(600, seed=5), dict(use_cuaev=True, use_single=False)
+    else:   # a brick of a two-rank decomposition: real ghosts of another rank, many rows without any
+        p, sysm, grid, rank = model_cache("ani2x", 1, 2024), hx.spatial_sort(hx.water_box(24000, seed=8)), (2, 1, 1), 1
+    inp = hx.decompose(sysm, grid, rank)
+    d = _device_inputs(inp, dev)
+    nt, nl = inp.ntotal, inp.nlocal
+    ani = ani_hip.ANI(p, 0, -1, use_fullnbr=True, **kw)
+    ani.set_option("device_overwrite_forces", 1)
+    f_ref = torch.full((nt * 3,), float("nan"), dtype=torch.float64, device=dev)
+    ev_ref = torch.zeros(10, dtype=torch.float64, device=dev)
+    ea_ref = torch.zeros(nl, dtype=torch.float64, device=dev)
+    ani.compute_device(nt, nl, d["species"].data_ptr(), d["x"].data_ptr(), inp.npairs, d["ilist"].data_ptr(), d["jlist"].data_ptr(),
+                       d["numneigh"].data_ptr(), 0, f_ref.data_ptr(), ev_ref.data_ptr(), ea_ref.data_ptr(), eflag_atom=eatom, vflag=vflag)
+    torch.cuda.synchronize()
+    for rep in range(2):   # twice: the second step reuses the row classes of the epoch
+        x = d["x"].clone()
+        ghosts = x[3 * nl:].clone()
+        x[3 * nl:] = float("nan")                   # part 1 must not read a ghost position
+        f = torch.full((nt * 3,), float("nan"), dtype=torch.float64, device=dev)
+        ev = torch.full((10,), float("nan"), dtype=torch.float64, device=dev)
+        ea = torch.zeros(nl, dtype=torch.float64, device=dev)
+        ani.step_begin(nt, nl, x.data_ptr(), f.data_ptr(), ev.data_ptr(), ea.data_ptr(), eflag_atom=eatom, vflag=vflag)
+        torch.cuda.synchronize()
+        x[3 * nl:] = ghosts                          # "the forward exchange"
+        ani.step_ghosts_ready()
+        torch.cuda.synchronize()
+        f_ghost = f[3 * nl:].clone()                 # "the reverse exchange" reads these now
+        ani.step_finish()
+        torch.cuda.synchronize()
+        assert torch.equal(f_ghost, f[3 * nl:])      # part 3 left the ghost rows alone
+        # same arithmetic; fp32 atomics in another order (the random box with the repulsion wall has forces of 1e3 and more)
+        tol = 1e-9 if case == "double" else 2e-4 + 2e-6 * float(f_ref.abs().max())
+        assert float((f - f_ref).abs().max()) < tol, case
+        assert abs(float(ev[0] - ev_ref[0])) < (1e-8 if case == "double" else 1e-3 * max(1.0, nl / 1000.0))
+        if vflag:
+            assert float((ev[1:] - ev_ref[1:]).abs().max()) < 1e-5 * float(ev_ref[1:].abs().max()) + 1e-2
+        if eatom:
+            assert float((ea - ea_ref).abs().max()) < 1e-4
+    if case == "two_bricks":
+        v = ani.debug_view()
+        assert v.nrows > 0
+    # protocol errors are reported, not executed
+    with pytest.raises(ani_hip.AniError, match="without ani_step_begin"):
+        ani.step_ghosts_ready()
+    with pytest.raises(ani_hip.AniError, match="without ani_step_ghosts_ready"):
+        ani.step_finish()
+    ani.close()
