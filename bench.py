@@ -58,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--dense-aev", action="store_true", help="keep the AEV columns of absent species (full 1008-wide rows)")
     ap.add_argument("--no-dense-pass", action="store_true", help="skip the extra timed pass with the full-width AEV")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (10 002 atoms x 8 members, combustion box)")
+    ap.add_argument("--overlap", action="store_true", help="MD loop: ghost exchanges on a second stream beside the rows without "
+                    "ghosts (ani_step_begin / _ghosts_ready / _finish); also ANI_MD_OVERLAP=1")
     ap.add_argument("--no-md", action="store_true", help="hot path only: `value` is then the static-position rate (development runs)")
     ap.add_argument("--repulsion", action="store_true", help="model with the optional pairwise repulsion block (not the headline configuration)")
     return ap.parse_args(argv)
@@ -239,7 +241,8 @@ def main():
         apply_env_options(ani)
         if args.dense_aev:
             ani.set_option("prune_absent_species", 0)
-        run = md.VerletRun(ani, inp, system.boxhi - system.boxlo, dev, dt=0.5, langevin=(300.0, 100.0), box_lo=system.boxlo, grid=grid)
+        run = md.VerletRun(ani, inp, system.boxhi - system.boxlo, dev, dt=0.5, langevin=(300.0, 100.0), box_lo=system.boxlo, grid=grid,
+                           overlap=True if args.overlap else None)
         run.create_velocities(300.0)
         for _ in range(warmup):
             run.step()
@@ -260,7 +263,7 @@ def main():
         natoms_all = run._allreduce_sum(torch.tensor([float(run.nlocal)], dtype=torch.float64, device=dev))
         info = {"steps": steps, "ms_per_step": dt / steps * 1e3, "list_rebuilds": run.nbuilds - b0,
                 "npairs_rank0": run.npairs, "nlocal_rank0": run.nlocal, "nghost_rank0": run.ntotal - run.nlocal,
-                "temperature_K": 2.0 * ke / (3.0 * natoms_all - 3.0) / md.BOLTZ,
+                "temperature_K": 2.0 * ke / (3.0 * natoms_all - 3.0) / md.BOLTZ, "exchange_overlap": bool(run._overlap),
                 "energy_finite": bool(np.isfinite(run.potential_energy()))}
         view = ani.debug_view()
         ani.close()

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 NATOMS, STEPS, DT, VSIGMA = 1536, 80, 0.25, 0.03  # fastest atom ~0.11 A/fs: a re-neighbouring (with migration) every ~40 steps
 
 
-def _run(rank, world, port, model_path, out_dir):
+def _run(rank, world, port, model_path, out_dir, overlap=False):
     sys.path.insert(0, ROOT)
     import _pkg
     _pkg.load()
@@ -29,7 +29,8 @@ def _run(rank, world, port, model_path, out_dir):
     sysm = hx.spatial_sort(hx.water_box(NATOMS))
     inp = hx.decompose(sysm, comm.grid_for(world), rank)
     ani = ani_hip.ANI(model_path, 0)
-    run = md.VerletRun(ani, inp, sysm.boxhi - sysm.boxlo, torch.device("cuda:0"), dt=DT, box_lo=sysm.boxlo)
+    run = md.VerletRun(ani, inp, sysm.boxhi - sysm.boxlo, torch.device("cuda:0"), dt=DT, box_lo=sysm.boxlo, overlap=overlap)
+    assert run._overlap == bool(overlap)
     # the same start velocities whatever the decomposition: a table indexed by global atom tag
     table = np.random.default_rng(99).normal(0.0, VSIGMA, size=(sysm.natoms, 3))
     run.v = torch.as_tensor(table[run.tag.cpu().numpy()], dtype=torch.float64, device="cuda:0")
@@ -44,7 +45,10 @@ def _run(rank, world, port, model_path, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_md_follows_single_rank(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True], ids=["plain", "overlapped-exchange"])
+def test_two_rank_md_follows_single_rank(overlap, tmp_path):
+    """overlapped-exchange: the two ghost exchanges of a step run on a second stream beside the rows that have no ghost
+    among their candidates (the library's three-call step, include/ani_hip.h ani_step_*)."""
     sys.path.insert(0, ROOT)
     import _pkg
     _pkg.load()
@@ -53,7 +57,7 @@ def test_two_rank_md_follows_single_rank(tmp_path):
     mf.write_model(path, mf.synthetic_model("ani2x", 1, seed=1, out_scale=0.02))
     port = 29500 + (os.getpid() % 2000) + 7
     mp.spawn(_run, args=(1, port, path, str(tmp_path)), nprocs=1, join=True)
-    mp.spawn(_run, args=(2, port, path, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_run, args=(2, port, path, str(tmp_path), overlap), nprocs=2, join=True)
     one = np.load(tmp_path / "w1_r0.npz")
     two = [np.load(tmp_path / f"w2_r{r}.npz") for r in range(2)]
     assert int(two[0]["builds"]) >= 3      # set-up + at least two re-neighbourings with atom migration
