@@ -43,8 +43,9 @@ class VerletRun:
         (T_target, damp_fs) as ``fix langevin T T damp seed``; grid: processor grid (default comm.grid_for(world));
         ghost_margin: ignored (kept for callers of the earlier fixed-ghost-shell version); overlap: run the two ghost
         exchanges of a step on a second stream beside the rows that do not need them (the library's split step,
-        include/ani_hip.h ani_step_*); default off: cutting the step costs five more launches (+0.05 ms at 12 500 atoms
-        per GPU on one card), which the hidden exchanges have to pay back (environment ANI_MD_OVERLAP=1 switches it on)."""
+        include/ani_hip.h ani_step_*).  Cutting the step costs five more launches (+0.05 ms at 12 500 atoms per GPU,
+        measured on one card), which the hidden exchanges have to pay back: default on with several ranks over RCCL (two
+        latency-bound all-to-alls per step), off otherwise; environment ANI_MD_OVERLAP=0/1 overrides the default."""
         from .comm import DomainComm, grid_for
         self.ani, self.device, self.group = ani, device, group
         world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -82,7 +83,8 @@ class VerletRun:
             self._recvbuf = torch.empty((0, 3), dtype=torch.float64, device=device)
             ani.set_option("device_overwrite_forces", 1)   # no separate force_clear launch
         env = os.environ.get("ANI_MD_OVERLAP")
-        want = False if overlap is None else bool(overlap)
+        nccl = world > 1 and dist.get_backend(group) == "nccl"
+        want = nccl if overlap is None else bool(overlap)
         if env is not None and overlap is None:
             want = env not in ("", "0")
         self._overlap = bool(want and self._fused)
