@@ -124,8 +124,11 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
  *                          forward exchange): the centres with ghosts, the MLP of every centre, then the backward pass
  *                          of the centres with ghosts; when its work is done the GHOST rows of d_f are final (no other
  *                          centre touches a ghost atom) and the reverse exchange can start.
- *   ani_step_finish        backward pass of the centres without ghosts; rows [0, nlocal) of d_f, energy, virial, per-atom
- *                          energies.
+ *                          (The backward pass of the centres WITHOUT ghosts is started here as well, on a less urgent
+ *                          stream of the library's own, beside the one of the centres with ghosts: both only wait for the
+ *                          MLP, the ghost forces still come first, and two half-size kernels side by side end sooner
+ *                          than one after the other.)
+ *   ani_step_finish        waits for that pass; rows [0, nlocal) of d_f, energy, virial, per-atom energies.
  * Arguments as ani_compute_full_device with ago != 0 (the list of the epoch must be in place: ani_build_list_device or a
  * call with ago == 0).  The three calls may use different streams if the caller orders them with events; results equal
  * those of the one-call step up to the order of the fp32 force atomics.  Models or precisions without the fast kernels

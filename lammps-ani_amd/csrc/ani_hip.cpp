@@ -111,6 +111,10 @@ struct ani_handle {
   int n_boundary = 0;
   bool classes_valid = false;
   int split_phase = 0;          // 0: no split step open, 1: begun, 2: ghosts done
+  // the backward pass of the rows without ghosts runs on a low-priority side stream beside the one of the rows with
+  // ghosts (both only wait for the MLP): the ghost forces are still done first, and the two kernels share one tail
+  hipStream_t side = nullptr;
+  hipEvent_t ev_mlp = nullptr, ev_side = nullptr;
   struct { const double* d_x; int eflag_atom, vflag; double *d_f, *d_ev, *d_eatom; } split{};
   int nlocal = 0, ntotal = 0, nrows = 0;
   long long npairs = 0;
@@ -908,6 +912,9 @@ void ani_destroy(ani_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  if (h->ev_mlp) (void)hipEventDestroy(h->ev_mlp);
+  if (h->ev_side) (void)hipEventDestroy(h->ev_side);
   for (auto& n : h->nets) {
     for (float* p : n.W) if (p) (void)hipFree(p);
     for (float* p : n.b) if (p) (void)hipFree(p);
@@ -1030,9 +1037,23 @@ int ani_step_ghosts_ready(ani_handle* h, void* stream) {
   const AevArgs a = step_aev_args(h, c, 1);
   int rc = step_compact_forward(h, a, st);
   if (!rc) rc = compute_mlp(h, st);
-  if (!rc) rc = step_backward(h, c, a, st);
+  if (rc) { h->split_phase = 0; return rc; }
+  if (!h->side) {
+    int lo = 0, hi = 0;
+    HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = the numerically largest value = the least urgent
+    HIP_TRY(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_mlp, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
+  }
+  HIP_TRY(h, hipEventRecord(h->ev_mlp, st));
+  rc = step_backward(h, c, a, st);
   if (rc) { h->split_phase = 0; return rc; }
   step_finish(h, c, h->nlocal, h->ntotal, false, st);   // the ghost atoms' forces are complete: no other row touches them
+  // the other rows' backward pass, beside the above (launched second, on the less urgent stream)
+  HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_mlp, 0));
+  rc = step_backward(h, c, step_aev_args(h, c, 2), h->side);
+  if (rc) { h->split_phase = 0; return rc; }
+  HIP_TRY(h, hipEventRecord(h->ev_side, h->side));
   HIP_TRY(h, hipGetLastError());
   return ANI_OK;
 }
@@ -1045,9 +1066,8 @@ int ani_step_finish(ani_handle* h, void* stream) {
   h->split_phase = 0;
   if (!split_supported(h)) return ANI_OK;
   const StepCtx c = split_ctx(h);
-  TraceRange tr("ani: step, backward pass of the rows without ghosts + finish");
-  const int rc = step_backward(h, c, step_aev_args(h, c, 2), st);
-  if (rc) return rc;
+  TraceRange tr("ani: step, finish");
+  HIP_TRY(h, hipStreamWaitEvent(st, h->ev_side, 0));   // the backward pass launched by ani_step_ghosts_ready on the side stream
   step_finish(h, c, 0, h->nlocal, true, st);
   HIP_TRY(h, hipGetLastError());
   if (h->profiling) HIP_TRY(h, hipStreamSynchronize(st));

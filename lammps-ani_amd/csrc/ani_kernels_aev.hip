@@ -27,6 +27,11 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <map>
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "ani_kernels.h"
 
 namespace ani {
@@ -1432,9 +1437,21 @@ template <typename K>
 static int persistent_blocks(K kernel, int nrows, int waves_per_block, size_t lds_bytes) {
   // resident workgroups per CU by registers AND LDS; a grid larger than what is resident would run a second,
   // mostly empty round of persistent workgroups
+  // the occupancy query costs microseconds of host time per launch: asked once per (kernel, LDS size)
+  static std::map<std::pair<const void*, size_t>, int> cache;
+  static std::mutex mtx;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * waves_per_block, lds_bytes) != hipSuccess || per_cu < 1)
-    per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+  {
+    std::lock_guard<std::mutex> lock(mtx);
+    const auto key = std::make_pair((const void*)kernel, lds_bytes);
+    const auto it = cache.find(key);
+    if (it != cache.end()) per_cu = it->second;
+    else {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64 * waves_per_block, lds_bytes) != hipSuccess || per_cu < 1)
+        per_cu = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+      cache[key] = per_cu;
+    }
+  }
   if (per_cu > 8) per_cu = 8;
   static const int forced = [] { const char* e = getenv(waves_env()); return e ? atoi(e) : 0; }();
   if (forced > 0 && forced * waves_per_block / 2 >= 1) per_cu = std::min(per_cu, std::max(1, forced / waves_per_block));
@@ -1447,8 +1464,16 @@ static int persistent_blocks(K kernel, int nrows, int waves_per_block, size_t ld
 template <typename K, typename... Extra>
 static void launch_fast(K kernel, const AevParams& p, const AevArgs& a, int waves, size_t lds, int cap, int rowf, hipStream_t st,
                         Extra... extra) {
-  // raising the dynamic-LDS limit is per kernel; every instantiation passes through here once
-  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // raising the dynamic-LDS limit is per kernel: once per instantiation
+  static std::set<std::pair<int, const void*>> raised;   // per device: a process may drive several
+  static std::mutex mtx;
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mtx);
+    if (raised.insert(std::make_pair(dev, (const void*)kernel)).second)
+      (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
   hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.kcount, waves, lds)), dim3(64 * waves), lds, st, p, a, cap, rowf,
                      extra...);
 }

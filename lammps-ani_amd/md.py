@@ -89,7 +89,9 @@ class VerletRun:
             want = env not in ("", "0")
         self._overlap = bool(want and self._fused)
         if self._overlap:
-            self._comm_stream = torch.cuda.Stream(device=device)
+            # ANI_MD_OVERLAP_ONE_STREAM: measurement knob, the same cut step with everything on the compute stream
+            self._comm_stream = torch.cuda.current_stream(device) if os.environ.get("ANI_MD_OVERLAP_ONE_STREAM") else \
+                torch.cuda.Stream(device=device)
             self._ev = [torch.cuda.Event() for _ in range(4)]
         self._build_list()
         self._forces()
