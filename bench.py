@@ -307,6 +307,8 @@ def main():
         steps = args.steps
         ms_per_step = dt / steps * 1e3
         ns_day = steps / dt * 0.0432
+        if phases["calls"] == 0:   # the cut step of the overlapped exchange records no phase events: the hot-path pass has them
+            phases = ph_hot
         calls = max(phases["calls"], 1)
         t_cmp, t_fwd, t_mlp, t_bwd, t_other = (phases[k] / calls for k in ("compact", "aev_fwd", "mlp", "aev_bwd", "other"))
         counts = np.bincount(system.types - 1, minlength=model.num_species) * (nl / system.natoms)
