@@ -25,6 +25,7 @@
 
 #include "atom.h"
 #include "comm.h"
+#include "domain.h"
 #include "error.h"
 #include "force.h"
 #include "memory.h"
@@ -173,12 +174,18 @@ void PairANI::compute(int eflag, int vflag) {
     if (ago == 0) {
       species.resize(ntotal);
       for (int i = 0; i < ntotal; i++) species[i] = type[i] - 1;
-      // a box around owned atoms and ghosts for the cell grid (any box does: atoms outside are clamped into edge cells)
+      // a box around owned atoms and ghosts for the cell grid (any box does: atoms outside are clamped into edge cells):
+      // the rank's sub-box widened by the ghost cutoff, which LAMMPS has at hand; a triclinic box keeps both in lamda
+      // coordinates, so there the positions are scanned
       double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1};
       for (int k = 0; k < 3; k++) {
-        double a = ntotal > 0 ? x[0][k] : 0.0, b = a;
-        for (int i = 1; i < ntotal; i++) { a = x[i][k] < a ? x[i][k] : a; b = x[i][k] > b ? x[i][k] : b; }
-        lo[k] = a - 0.25; hi[k] = b + 0.25;
+        if (!domain->triclinic) {
+          lo[k] = domain->sublo[k] - comm->cutghost[k] - 0.25; hi[k] = domain->subhi[k] + comm->cutghost[k] + 0.25;
+        } else {
+          double a = ntotal > 0 ? x[0][k] : 0.0, b = a;
+          for (int i = 1; i < ntotal; i++) { a = x[i][k] < a ? x[i][k] : a; b = x[i][k] > b ? x[i][k] : b; }
+          lo[k] = a - 0.25; hi[k] = b + 0.25;
+        }
       }
       if (ntotal > 0 &&
           ani_build_list(ani, ntotal, nlocal, species.data(), &x[0][0], cutoff + neighbor->skin, lo, hi, &npairs) != ANI_OK)

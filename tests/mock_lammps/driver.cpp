@@ -89,6 +89,18 @@ int mock_compute(void* h, int nlocal, int nghost, const double* x, const int* ty
       s->pair->list = &s->list;
       s->lmp.comm->owner.assign(owner, owner + nghost);
       s->lmp.comm->nlocal = nlocal;
+      // what Domain / Comm hold in a real run: the sub-box of the owned atoms and the ghost cutoff around it
+      for (int k = 0; k < 3; k++) {
+        double lo = nlocal > 0 ? x[k] : 0.0, hi = lo, glo = lo, ghi = lo;
+        for (int i = 0; i < nt; i++) {
+          const double v = x[3 * (size_t)i + k];
+          if (i < nlocal) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+          glo = v < glo ? v : glo; ghi = v > ghi ? v : ghi;
+        }
+        s->lmp.domain->sublo[k] = lo; s->lmp.domain->subhi[k] = hi;
+        const double ext = (lo - glo) > (ghi - hi) ? (lo - glo) : (ghi - hi);
+        s->lmp.comm->cutghost[k] = ext > 0.0 ? ext : 0.0;
+      }
     }
     s->lmp.neighbor->ago = ago;
     s->pair->compute(eflag, vflag);

@@ -94,7 +94,14 @@ class Comm {
   // single-rank periodic reverse communication: ghost g -> owner[g]
   std::vector<int> owner;
   int nlocal = 0;
+  double cutghost[3] = {0, 0, 0};   // ghost cutoff per dimension (comm.h)
   void reverse_comm(Pair* p);
+};
+
+class Domain {   // the members of domain.h the adapter reads
+ public:
+  int triclinic = 0;
+  double sublo[3] = {0, 0, 0}, subhi[3] = {0, 0, 0};
 };
 
 class LAMMPS {
@@ -104,6 +111,7 @@ class LAMMPS {
   Update* update = new Update;
   Neighbor* neighbor = new Neighbor;
   Comm* comm = new Comm;
+  Domain* domain = new Domain;
   Error* error = new Error;
   Memory* memory = new Memory;
   MPI_Comm world = 0;
@@ -112,8 +120,8 @@ class LAMMPS {
 class Pointers {
  public:
   explicit Pointers(LAMMPS* p)
-      : lmp(p), atom(p->atom), force(p->force), update(p->update), neighbor(p->neighbor), comm(p->comm), error(p->error),
-        memory(p->memory), world(p->world) {}
+      : lmp(p), atom(p->atom), force(p->force), update(p->update), neighbor(p->neighbor), comm(p->comm), domain(p->domain),
+        error(p->error), memory(p->memory), world(p->world) {}
   virtual ~Pointers() = default;
 
  protected:
@@ -123,6 +131,7 @@ class Pointers {
   Update*& update;
   Neighbor*& neighbor;
   Comm*& comm;
+  Domain*& domain;
   Error*& error;
   Memory*& memory;
   MPI_Comm& world;
