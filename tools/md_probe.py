@@ -17,6 +17,9 @@ model_file.write_model(path, model_file.synthetic_model("ani2x", 1, seed=1, out_
 sysm = harness.spatial_sort(harness.water_box(natoms))
 inp = harness.decompose(sysm, skin=2.0 + margin)
 ani = ani_hip.ANI(path, 0, use_single=bool(single))
+if os.environ.get("MLP_ARITH"):   # 2 (default): two-term fp16 splits, 1: exact bf16 splits, 0: fp32-input MFMA
+    ani.set_option("mlp_arith", int(os.environ["MLP_ARITH"]))
+    print("mlp_arith", os.environ["MLP_ARITH"])
 dev = torch.device("cuda:0")
 run = md.VerletRun(ani, inp, sysm.boxhi - sysm.boxlo, dev, dt=dt, ghost_margin=margin, box_lo=sysm.boxlo, langevin=lang)
 # list check against the harness at set-up
@@ -31,6 +34,5 @@ for s in range(1, steps + 1):
     run.step()
     if s % max(1, steps // 10) == 0:
         pe, ke = run.potential_energy(), run.kinetic_energy()
-        moved = float((run.x[:run.nlocal] - run.x_setup).square().sum(1).max()) ** 0.5
-        print(f"step {s} pe {pe:.4f} ke {ke:.4f} etot {pe+ke:.4f} drift {pe+ke-e0:+.5f} T {2*ke/(3*run.nlocal-3)/md.BOLTZ:.1f} builds {run.nbuilds} moved {moved:.2f}")
+        print(f"step {s} pe {pe:.4f} ke {ke:.4f} etot {pe+ke:.4f} drift {pe+ke-e0:+.5f} T {2*ke/(3*run.nlocal-3)/md.BOLTZ:.1f} builds {run.nbuilds}")
 torch.cuda.synchronize(); print("ms/step", (time.time() - t0) / steps * 1e3)
