@@ -65,7 +65,7 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])   # 8 = the 2 x 2 x 2 bricks of the 8-GPU node: every rank borders every other
 def test_domain_comm_matches_harness(world, tmp_path):
     hx, s = _system()
     from lammps_ani_amd import comm
