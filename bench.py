@@ -362,8 +362,11 @@ def main():
                         bytes_per_launch=bf, valu_frac=valu("ani::aev_forward", t_fwd))
         fwd_roof["frac"] = fwd_roof["achieved"] / PEAK_HBM_GBS if fwd_roof["achieved"] else None
         mlp_roof = dict(bound="mfma", achieved=flops / (t_mlp * 1e-3) / 1e12 if t_mlp > 0 else None, peak=PEAK_F32_MFMA_TFLOPS,
-                        unit="TFLOP/s", traffic=hbm_traffic("ani::gemm_grouped"),
-                        kernel="gemm_grouped_x3 (MLP forward + backward: 6 grouped launches per step, all species and members)",
+                        unit="TFLOP/s",
+                        traffic=(hbm_traffic("ani::mlp_pipeline") or hbm_traffic("ani::gemm_grouped") or hbm_traffic("ani::mlp_chain")),
+                        kernel="MLP forward + backward, six products: mlp_pipeline_x2 (one launch of persistent workgroups over "
+                               "(layer, tile) items; one member, large systems), mlp_chain_x3 (one chained launch; small systems) or "
+                               "six gemm_grouped_x3 launches (several members, wide layers)",
                         ms_per_step=t_mlp, flops_per_step=flops, flops_per_step_full_width_aev=flops_dense, aev_columns=aev_cols,
                         note="achieved = algorithmic fp32 flops / time, peak = the fp32-input MFMA peak.  The kernel evaluates each "
                              "fp32 product as three v_mfma_f32_32x32x16_f16 products of two-term fp16 splits of the power-of-two "

@@ -92,6 +92,8 @@ struct ani_handle {
   SpeciesMap cmap{};  // species -> index among the species present
   int active_mask = -1;
   bool prune = true;  // ani_set_option("prune_absent_species")
+  int mlp_pipeline = 1;   // ani_set_option("mlp_pipeline"): 1 = large systems run all MLP layers as one launch of persistent workgroups
+                          // with per-tile dependencies, 2 = at any size (measurement knob), 0 = one launch per layer
   int mlp_chain = 1;   // ani_set_option("mlp_chain"): 1 = one chained launch for the MLP of small systems, 2 = at any size, 0 = never
   ChainPlan chain_plan;
   bool profiling = false;  // ani_set_option("profiling"): every entry point synchronises its stream before returning
@@ -564,23 +566,35 @@ int compute_mlp(ani_handle* h, hipStream_t st) {
   }
   layer_probs.push_back(probs); layer_epi.push_back(EPI_PLAIN);
 
-  // small systems, one ensemble member, split-bf16 arithmetic: the whole MLP as one chained launch (a workgroup takes
-  // its 64-row tile through all layers); otherwise one grouped launch per layer
+  // One ensemble member, split arithmetic -- three ways to launch the six products:
+  //  * up to one round of chained workgroups (2 per CU; <= 512 64-row tiles = 32 000 water atoms): ONE chained launch, a
+  //    workgroup takes its tile through all layers (mlp_chain_x3);
+  //  * beyond (two-term arithmetic, layers no wider than 256): ONE launch of persistent workgroups over (layer, tile) items
+  //    with a completion flag per item (mlp_pipeline_x2) -- measured against the alternatives, MLP ms: 50 001 atoms 0.149
+  //    (chained 0.203), 75 000 0.206 (grouped 0.240), 100 002 0.281 (grouped 0.320); 25 002 atoms 0.113 against 0.095
+  //    chained;
+  //  * otherwise one grouped launch per layer (several members, the exact bf16 split with many tiles, wide layers).
   const int np = (int)layer_probs[0].size();
   int tiles = 0;
   for (const GemmArgs& g : layer_probs[0]) tiles += g.rows / 64;
-  // Which is faster is a matter of rounds: the chained kernel holds 2 workgroups per CU for all six products, a grouped
-  // launch 3 per CU for one.  Measured per round at the benchmark shapes: 0.106 ms (chain) and 0.137 ms (six launches);
-  // e.g. 780 tiles (50 000 water atoms) are 2 rounds either way -> chain; 1564 tiles are 4 against 3 -> grouped launches.
   const int cslots = mlp_chain_slots(), lslots = cslots + cslots / 2;
-  const bool chain_wins = tiles <= cslots || (tiles <= 2 * cslots &&   // beyond two rounds the two were within 4 %: launches
+  bool pipeline = h->mlp_pipeline && arith == MLP_F16X2 && M == 1 && np > 0 && (tiles > cslots || h->mlp_pipeline > 1) &&
+                  h->mlp_chain <= 1;
+  for (const auto& lp : layer_probs) {
+    pipeline = pipeline && (int)lp.size() == np;
+    for (const GemmArgs& g : lp) pipeline = pipeline && g.N <= 256 && g.batch == 1;
+  }
+  // without the pipeline the choice between chain and grouped launches is a matter of rounds (0.106 ms per chained round,
+  // 0.137 ms per round of six grouped launches at the benchmark shapes)
+  const bool chain_wins = tiles <= cslots || (tiles <= 2 * cslots &&
                                               0.106 * ((tiles + cslots - 1) / cslots) < 0.137 * ((tiles + lslots - 1) / lslots));
-  bool chain = h->mlp_chain && arith != MLP_FP32 && M == 1 && np > 0 && (h->mlp_chain > 1 || chain_wins);
+  bool chain = !pipeline && h->mlp_chain && arith != MLP_FP32 && M == 1 && np > 0 && (h->mlp_chain > 1 || chain_wins);
   for (const auto& lp : layer_probs) chain = chain && (int)lp.size() == np;
-  if (chain) {
+  if (chain || pipeline) {
     std::vector<GemmArgs> flat;
     for (const auto& lp : layer_probs) flat.insert(flat.end(), lp.begin(), lp.end());
-    HIP_TRY(h, launch_mlp_chain(flat.data(), layer_epi.data(), (int)layer_probs.size(), np, &h->chain_plan, st, arith));
+    HIP_TRY(h, launch_mlp_chain(flat.data(), layer_epi.data(), (int)layer_probs.size(), np, &h->chain_plan, st, arith, pipeline,
+                                h->err_flag.p));
   } else {
     for (size_t l = 0; l < layer_probs.size(); l++)
       launch_gemm_group(layer_probs[l].data(), (int)layer_probs[l].size(), (Epilogue)layer_epi[l], st, arith);
@@ -1286,6 +1300,11 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   }
   if (strcmp(name, "mlp_chain") == 0) {
     h->mlp_chain = value;
+    return ANI_OK;
+  }
+  if (strcmp(name, "mlp_pipeline") == 0) {
+    if (value < 0 || value > 2) { h->err = "mlp_pipeline must be 0, 1 or 2"; return ANI_ERR_ARG; }
+    h->mlp_pipeline = value;
     return ANI_OK;
   }
   if (strcmp(name, "mlp_arith") == 0) {

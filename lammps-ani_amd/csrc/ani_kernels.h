@@ -66,10 +66,16 @@ void launch_gemm_group(const GemmArgs* probs, int nprob, Epilogue epi, hipStream
 struct ChainPlan {
   void* d_desc = nullptr;      // device: GemmArgs[nlayers * nprob], then int epi[nlayers], int tile_start[nprob + 1]
   size_t bytes = 0;
+  int* d_done = nullptr;       // pipeline launch: one completion flag per (layer, tile)
+  size_t done_n = 0;
   std::vector<unsigned char> host;
 };
 // returns the HIP status of the descriptor upload (a failed allocation must not let the step run on stale activations)
-hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st, MlpArith arith);
+// pipeline = true (large systems, two-term arithmetic, layers no wider than 256): persistent workgroups walk (layer, tile)
+// items in layer-major order with a completion flag per item instead of a workgroup per tile (mlp_pipeline_x2); err_flag
+// gets bit 2 if a wait ever runs into its bound
+hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st, MlpArith arith,
+                            bool pipeline = false, int* err_flag = nullptr);
 void free_chain_plan(ChainPlan& p);
 int mlp_chain_slots();   // workgroups the chain kernel can keep resident (2 per CU)
 

@@ -50,7 +50,14 @@ __device__ __forceinline__ float dcelu_from_h(float h, float inv_alpha) {
 // Epilogues shared by the fp32-MFMA kernel and the split-bf16 kernel (same accumulator layout: col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).  `lds` is the workgroup's staging memory, free by now.
 // R: rows of the workgroup tile, WN: wave columns, wm: index of this accumulator's 32-row strip inside the tile.
-template <int R, int WN, int EPI, int NTW>
+// WT: the results are stored write-through to memory (device-scope stores), for a consumer on another XCD inside the same
+// launch (mlp_pipeline_x2): the L2 caches of the eight XCDs are not coherent with each other before a kernel ends
+template <bool WT>
+__device__ __forceinline__ void store_c(float* p, float v) {
+  if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <int R, int WN, int EPI, int NTW, bool WT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NTW], float* lds, int b, int n0, int row0, int t0,
                                               int tcnt, int wm, int wn, int lr, int lh) {
   const int N = g.N;
@@ -64,7 +71,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
-          C[(long long)m * g.ldc + n] = acc[nt][r];
+          store_c<WT>(&C[(long long)m * g.ldc + n], acc[nt][r]);
         }
       }
     }
@@ -78,7 +85,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
-          C[(long long)m * g.ldc + n] = celu_f(acc[nt][r] + bv, g.alpha, g.inv_alpha);
+          store_c<WT>(&C[(long long)m * g.ldc + n], celu_f(acc[nt][r] + bv, g.alpha, g.inv_alpha));
         }
       }
     }
@@ -92,7 +99,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
         for (int r = 0; r < 16; r++) {
           const int m = mbase + (r & 3) + 8 * (r >> 2);
           const float h = H[(long long)m * g.ldaux + n];
-          C[(long long)m * g.ldc + n] = acc[nt][r] * dcelu_from_h(h, g.inv_alpha);
+          store_c<WT>(&C[(long long)m * g.ldc + n], acc[nt][r] * dcelu_from_h(h, g.inv_alpha));
         }
       }
     }
@@ -117,7 +124,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
           const float h = celu_f(acc[nt][r] + bv, g.alpha, g.inv_alpha);
           esum[r] = fmaf(h, wv, esum[r]);
           // dE/dz = (1/M) * w_out * celu'(z)
-          C[(long long)m * g.ldc + n] = valid[r] * wv * dcelu_from_h(h, g.inv_alpha);
+          store_c<WT>(&C[(long long)m * g.ldc + n], valid[r] * wv * dcelu_from_h(h, g.inv_alpha));
         }
       }
     }
@@ -717,6 +724,142 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 2) void mlp_chain_x3(const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// All layers in ONE launch for large systems: persistent workgroups walk the items (layer, 64-row tile) in layer-major
+// order, item w to workgroup w mod G.  Tile t of layer l needs only tile t of layer l - 1 (same rows), finished a whole
+// layer of items earlier by another workgroup: a flag per item (release / acquire at device scope) carries the
+// dependency, and no launch has a tail of its own -- six launches of 1563 tiles on 768 slots are six third rounds of 27
+// tiles, this is 9378 items on 768 slots.  One ensemble member, layers no wider than 256, two-term arithmetic.
+// Items are drawn from counters (one returning atomic per item, requested while the previous item is being multiplied):
+// eight of them, counter c handing out the items c, c + 8, c + 16, ... to the workgroups with blockIdx % 8 == c (one
+// counter for all 768 workgroups cost 13 % of the kernel at 50 000 atoms; a static deal, item w to workgroup w mod G, is
+// as fast but deadlocks when something else keeps part of the grid from being resident).  Every workgroup takes its items
+// in increasing order and waits only for smaller ones, the dispatcher starts workgroups in index order (so every counter
+// has running takers): the smallest unfinished item can always proceed, no wait is circular.  A wait is bounded all the
+// same (about a second) and then raises the error flag.
+// The tile loop is the one of gemm_grouped_x3<2, *, 1, 1, 2> (two LDS stages, one barrier per slab).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void mlp_pipeline_x2(const GemmArgs* __restrict__ layers, const int* __restrict__ epi,
+                                                         const int* __restrict__ tile_start, int nlayers, int nprob, int total,
+                                                         int* __restrict__ done, int* __restrict__ err_flag) {
+  constexpr int P = 2, WN = 2, R = 64, NTW = 8 / WN, PB = 32 * P, ROW = PB + 16, NC = 2 * P, NB = NC;
+  constexpr int STAGE = (R + 256) * ROW;
+  __shared__ uint4 lds4[2 * STAGE / 16];
+  unsigned char* base = reinterpret_cast<unsigned char*>(lds4);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ar = tid >> 2, ak = (tid & 3) * 4;
+  __shared__ int s_next;
+  const int cq = blockIdx.x & 7;
+  int* ctr = done + (size_t)nlayers * total + cq;   // the eight item counters follow the flags
+  if (tid == 0) s_next = cq + 8 * atomicAdd(ctr, 1);
+  __syncthreads();
+  int w = s_next;
+  while (w < nlayers * total) {
+    int nxt = 0;
+    if (tid == 0) nxt = cq + 8 * atomicAdd(ctr, 1);   // the next item of this workgroup: in flight while this one is computed
+    const int l = w / total, t = w - l * total;
+    int pi = 0;
+    while (pi + 1 < nprob && t >= tile_start[pi + 1]) pi++;
+    const int tile_m = t - tile_start[pi];
+    if (l > 0) {
+      if (tid == 0) {
+        const int* f = done + (size_t)(l - 1) * total + t;
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(16);
+        if (spins >= (1 << 21)) atomicOr(err_flag, 2);
+      }
+      __syncthreads();
+      // the producer's stores went to memory and this XCD has never read these lines: only this CU's L1 is told
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    const GemmArgs g = layers[l * nprob + pi];
+    const int e = epi[l];
+    const int row0 = g.row0 + tile_m * R;
+    const int K = g.K, N = g.N;
+    const int ntiles = min(8, (N + 31) >> 5);
+    const int per = (ntiles + WN - 1) / WN;
+    const int t0 = wn * per;
+    const int tcnt = max(0, min(per, ntiles - t0));
+    const int brows = min(32 * ntiles, N);
+    const float* __restrict__ A = g.A + (long long)row0 * g.lda;
+    const float* __restrict__ Am = g.Amask ? g.Amask + (long long)row0 * g.lda : nullptr;
+    const uint4* __restrict__ B3 = reinterpret_cast<const uint4*>(g.Btp);
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+    float4 pa, pm;
+    uint4 pb[NB];
+    auto gload = [&](int kb) {
+      const int kc = kb * 16 + ak;
+      const bool in = kc < K;
+      pa = in ? *reinterpret_cast<const float4*>(A + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
+      if (Am) pm = in ? *reinterpret_cast<const float4*>(Am + (long long)ar * g.lda + kc) : make_float4(0, 0, 0, 0);
+      const uint4* src = B3 + (long long)kb * N * NC;
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int c = tid + 256 * i;
+        pb[i] = (kb < g.kbp && c < NC * brows) ? src[c] : make_uint4(0, 0, 0, 0);
+      }
+    };
+    auto stage_write = [&](unsigned char* As) {
+      unsigned char* Bs = As + R * ROW;
+      float4 av = pa;
+      if (Am) {
+        av.x *= dcelu_from_h(pm.x, g.inv_alpha); av.y *= dcelu_from_h(pm.y, g.inv_alpha);
+        av.z *= dcelu_from_h(pm.z, g.inv_alpha); av.w *= dcelu_from_h(pm.w, g.inv_alpha);
+      }
+      stage_a4<P>(As + ar * ROW + ak * 2, av, g.a_scale);
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int c = tid + 256 * i;
+        const int r = c / NC, q = c - NC * r;
+        if (r < 32 * ntiles) *reinterpret_cast<uint4*>(Bs + r * ROW + q * 16) = pb[i];
+      }
+    };
+    auto multiply = [&](const unsigned char* As) {
+      const unsigned char* Bs = As + R * ROW;
+      const Frag<P> af = load_frag<P>(As + (32 * wm + lr) * ROW + lh * 16);
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++) {
+        if (nt < tcnt) {
+          const Frag<P> bf = load_frag<P>(Bs + (32 * (t0 + nt) + lr) * ROW + lh * 16);
+          mma_planes<P>(af, bf, acc[nt]);
+        }
+      }
+    };
+    const int nkt = g.kbp;
+    const int rot = (int)(((unsigned)w * 11u) % (unsigned)nkt);
+    auto slab = [&](int kt) { int q = kt + rot; if (q >= nkt) q -= nkt; return q; };
+    gload(slab(0));
+    stage_write(base);
+    if (nkt > 1) gload(slab(1));
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt++) {
+      multiply(base + (kt & 1) * STAGE);
+      if (kt + 1 < nkt) stage_write(base + ((kt + 1) & 1) * STAGE);
+      if (kt + 2 < nkt) gload(slab(kt + 2));
+      __syncthreads();
+    }
+    unscale<P>(acc, g.inv_scale);
+    float* ldsf = reinterpret_cast<float*>(lds4);
+    if (e == EPI_CELU) gemm_epilogue<R, WN, EPI_CELU, NTW, true>(g, acc, ldsf, 0, 0, row0, t0, tcnt, wm, wn, lr, lh);
+    else if (e == EPI_LAST) gemm_epilogue<R, WN, EPI_LAST, NTW, true>(g, acc, ldsf, 0, 0, row0, t0, tcnt, wm, wn, lr, lh);
+    else gemm_epilogue<R, WN, EPI_PLAIN, NTW, true>(g, acc, ldsf, 0, 0, row0, t0, tcnt, wm, wn, lr, lh);
+    // this tile of this layer is complete: every thread's (write-through) stores have been acknowledged, then the flag.
+    // No device-scope release fence: on this chip it writes back the XCD's whole L2 (measured: the kernel 6x slower)
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt = lgkmcnt = expcnt = 0
+    if (tid == 0) s_next = nxt;
+    __syncthreads();   // also: the staging memory (scratch of the LAST epilogue) is reused by the next item
+    if (tid == 0) __hip_atomic_store(done + (size_t)l * total + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w = s_next;
+  }
+}
+
 int mlp_chain_slots() {
   static const int n = [] {
     int dev = 0, v = 256;
@@ -727,11 +870,14 @@ int mlp_chain_slots() {
 }
 
 void free_chain_plan(ChainPlan& p) {
+  if (p.d_done) (void)hipFree(p.d_done);
+  p.d_done = nullptr; p.done_n = 0;
   if (p.d_desc) (void)hipFree(p.d_desc);
   p.d_desc = nullptr; p.bytes = 0; p.host.clear();
 }
 
-hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st, MlpArith arith) {
+hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers, int nprob, ChainPlan* plan, hipStream_t st, MlpArith arith,
+                            bool pipeline, int* err_flag) {
   std::vector<int> tile_start(nprob + 1, 0);
   static const int forced_r = [] { const char* e = getenv("ANI_CHAIN_WAVES"); return e ? atoi(e) : 0; }();   // experiment knob: 4 / 8
   const int R = 64;
@@ -758,6 +904,28 @@ hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers,
     plan->host = host;
   }
   const unsigned char* d = reinterpret_cast<const unsigned char*>(plan->d_desc);
+  if (pipeline) {
+    const size_t nitems = (size_t)nlayers * total, nflags = nitems + 8;   // + the item counters
+    if (plan->done_n < nflags) {
+      if (plan->d_done) (void)hipFree(plan->d_done);
+      plan->d_done = nullptr; plan->done_n = 0;
+      const hipError_t e = hipMalloc((void**)&plan->d_done, nflags * sizeof(int));
+      if (e != hipSuccess) { plan->d_done = nullptr; return e; }
+      plan->done_n = nflags;
+    }
+    hipError_t e = hipMemsetAsync(plan->d_done, 0, nflags * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    static const int slots = [] {
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_pipeline_x2, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+      return per_cu * (mlp_chain_slots() / 2);
+    }();
+    const int grid = (int)std::max<size_t>(8, std::min<size_t>((size_t)slots, nitems));   // every counter needs a taker
+    hipLaunchKernelGGL(mlp_pipeline_x2, dim3(grid), dim3(256), 0, st, reinterpret_cast<const GemmArgs*>(d),
+                       reinterpret_cast<const int*>(d + b0), reinterpret_cast<const int*>(d + b0 + b1), nlayers, nprob, total,
+                       plan->d_done, err_flag);
+    return hipGetLastError();
+  }
   // no more tiles than CUs: one eight-wave workgroup per CU; otherwise two four-wave workgroups per CU
   const bool wide = forced_r == 8 || (forced_r != 4 && 2 * total <= mlp_chain_slots());
   auto go = [&](auto kernel, int threads) {

@@ -256,6 +256,39 @@ def test_chained_mlp_launch_equals_per_layer_launches(model_cache, hip):
         ani.close()
 
 
+@pytest.mark.parametrize("natoms", [3000, 24000, 60000])
+def test_mlp_pipeline_equals_per_layer_launches_on_changing_inputs(natoms, model_cache, hip):
+    """Large single-member systems run all MLP layers as ONE launch of persistent workgroups: tile t of layer l waits for a
+    completion flag of tile t of layer l - 1, whose results another workgroup -- possibly on another XCD, whose L2 is not
+    coherent with this one's inside a launch -- stored write-through.  A stale read would return the PREVIOUS step's
+    activations (the buffers are reused every step), which a benchmark on static positions cannot see: here the atoms
+    move between steps, and every step must match a handle that launches layer by layer.  Option mlp_pipeline = 2 forces
+    the path at sizes where it is not the default (fewer items than resident workgroups, about as many, several times)."""
+    p = model_cache("ani2x", 1, 2024)
+    sysm = hx.spatial_sort(hx.water_box(natoms, seed=11))
+    inp = hx.decompose(sysm)
+    piped, layered = hip.ANI(p, 0), hip.ANI(p, 0)
+    for h, v in ((piped, 2), (layered, 0)):
+        h.set_option("mlp_chain", 0)
+        h.set_option("mlp_pipeline", v)
+    rng = np.random.default_rng(3)
+    direction = rng.normal(size=(inp.nlocal, 3))
+    prev = None
+    for step in range(5):
+        disp = np.zeros_like(inp.x)
+        disp[: inp.nlocal] = 0.03 * step * direction
+        disp[inp.nlocal:] = disp[inp.owner_lidx]
+        moved = hx.RankInput(**{**inp.__dict__, "x": inp.x + disp})
+        a, b = piped.compute(moved, ago=step), layered.compute(moved, ago=step)
+        assert np.isfinite(a["energy"])
+        assert np.abs(a["force"] - b["force"]).max() < 2e-4, step
+        assert np.abs(a["eatom"] - b["eatom"]).max() < 1e-4
+        if prev is not None:   # the steps really differ: a stale activation would show
+            assert np.abs(a["force"] - prev).max() > 0.05
+        prev = a["force"]
+    piped.close(); layered.close()
+
+
 def test_energy_is_extensive_under_periodic_replication(model_cache, hip):
     """Two periodic copies of a box side by side: E = 2 E(base) and every atom's force repeats -- a property that needs
     no oracle (tools/big_probe.py runs it with 8 copies = 10^6 atoms).  The copy sits a box length away from the origin:

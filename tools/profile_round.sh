@@ -35,7 +35,7 @@ summary = {"source_digest": bench.source_digest(), "workload": "water-100002, 1 
            "kernels": kern}
 json.dump(summary, open(out_dir + "/pmc_summary.json", "w"), indent=1, sort_keys=True)
 for n in sorted(kern):
-    if any(k in n for k in ("aev_", "nbr_compact", "gemm_grouped")):
+    if any(k in n for k in ("aev_", "nbr_compact", "gemm_grouped", "mlp_")):
         print(n[:60], {c: round(x["mean_per_launch"] / 1e6, 2) for c, x in sorted(kern[n].items())})
 PY
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
