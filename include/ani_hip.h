@@ -178,6 +178,10 @@ typedef struct {
   int species_count[16];           /* centres per species */
   int aev_stride;                  /* floats per row of d_aev / d_gaev */
   int aev_active_length;           /* columns in use: the AEV entries of the species present in the system */
+  int error_flags;                 /* every bit the device error word has shown so far (latched at host reads and at each
+                                      re-neighbouring): 1 = LDS neighbour capacity exceeded, 2 = a wait inside the
+                                      one-launch MLP kernel timed out.  The device entry points cannot return these (nothing
+                                      synchronises; the energy becomes NaN): a loop that finds a NaN energy reads this */
 } ani_debug_view;
 int ani_debug_get(ani_handle* h, ani_debug_view* out);
 /* out[c], c < aev_active_length: column of the model's full AEV that column c of d_aev holds */

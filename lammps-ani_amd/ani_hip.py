@@ -31,7 +31,7 @@ class AniError(RuntimeError):
 class DebugView(C.Structure):
     _fields_ = [("nlocal", C.c_int), ("ntotal", C.c_int), ("nrows", C.c_int), ("npairs", C.c_int64),
                 ("d_aev", C.c_void_p), ("d_gaev", C.c_void_p), ("d_row_of_centre", C.c_void_p),
-                ("species_count", C.c_int * 16), ("aev_stride", C.c_int), ("aev_active_length", C.c_int)]
+                ("species_count", C.c_int * 16), ("aev_stride", C.c_int), ("aev_active_length", C.c_int), ("error_flags", C.c_int)]
 
 
 def build(force: bool = False) -> str:

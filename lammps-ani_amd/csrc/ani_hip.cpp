@@ -12,11 +12,18 @@
 #include "../../include/ani_hip.h"
 
 #include <hip/hip_runtime.h>
+#ifndef ANI_NO_ROCTX
 #include <rocprofiler-sdk-roctx/roctx.h>
+#else   // built without the profiler SDK: the markers (only profiling runs look at them) become no-ops
+static inline void roctxRangePushA(const char*) {}
+static inline void roctxRangePop() {}
+static inline void roctxMarkA(const char*) {}
+#endif
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,6 +32,12 @@
 #include "ani_model.h"
 
 using namespace ani;
+
+namespace ani {
+static thread_local hipError_t g_launch_error = hipSuccess;
+void note_launch_error(hipError_t e) { if (e != hipSuccess && g_launch_error == hipSuccess) g_launch_error = e; }
+hipError_t take_launch_error() { const hipError_t e = g_launch_error; g_launch_error = hipSuccess; return e; }
+}  // namespace ani
 
 namespace {
 
@@ -98,7 +111,9 @@ struct ani_handle {
   ChainPlan chain_plan;
   bool profiling = false;  // ani_set_option("profiling"): every entry point synchronises its stream before returning
   bool dev_overwrite = false;  // ani_set_option("device_overwrite_forces"): ani_compute_full_device writes d_f instead of adding
-  MlpArith mlp_arith = MLP_F16X2;  // ani_set_option("mlp_arith"): how the MLP evaluates its fp32 products (ani_kernels.h)
+  MlpArith mlp_arith = MLP_BF16X3;  // ani_set_option("mlp_arith"): how the MLP evaluates its fp32 products (ani_kernels.h); the exact
+                                   // split is the default, the reduced-precision fp16 split an opt-in -- the mapping of the reference's
+                                   // TF32 switch (off unless LAMMPS_ANI_ALLOW_TF32, src/ani_csrc/ani.cpp:41-43)
   std::vector<int> colmap;  // ap_run column -> ap column
   int device = 0;
   bool use_cuaev = true, use_fullnbr = true, use_single = true;
@@ -122,6 +137,7 @@ struct ani_handle {
   long long npairs = 0;
   int count[kMaxSpecies] = {0}, row_start[kMaxSpecies] = {0};
 
+  int sticky_flags = 0;   // every bit the device error word has ever shown the host (bit 1: LDS capacity, bit 2: MLP wait timeout)
   int max_numneigh = 0;
   DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
   DevBuf<float4> xyzs, cl_xyz;
@@ -388,12 +404,21 @@ int rebuild(ani_handle* h, hipStream_t st) {
   HIP_TRY(h, h->bucket_info.reserve(kBucketInfoInts));
   // a capacity overflow of an earlier epoch must not poison this one (the flag turns the device path's energy into NaN)
   HIP_TRY(h, h->err_flag.reserve(1, true));
+  {
+    // ... but what it said is kept: the device path only turns the energy into NaN, and a caller that looks at the energy
+    // every few steps must still be able to tell a capacity overflow from a stalled kernel (ani_debug_get: error_flags)
+    int flag = 0;
+    HIP_TRY(h, hipMemcpyAsync(&flag, h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    h->sticky_flags |= flag;
+  }
   HIP_TRY(h, hipMemsetAsync(h->err_flag.p, 0, sizeof(int), st));
   PrepOut o{h->nbr_off.p, h->row_of_centre.p, h->centre_of_row.p, h->row_info.p, h->bucket_info.p};
   launch_prepare(h->species.p, h->ilist.p, h->numneigh.p, nlocal, h->ntotal, m.S, nrows_cap, o, st);
   int info[kBucketInfoInts];
   HIP_TRY(h, hipMemcpyAsync(info, h->bucket_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
   HIP_TRY(h, hipStreamSynchronize(st));
+  HIP_TRY(h, take_launch_error());
   if (info[2 * kMaxSpecies + 1]) { h->err = "an atom has a species outside the model's species list (or ilist holds an index outside [0, ntotal))"; return ANI_ERR_ARG; }
   for (int s = 0; s < m.S; s++) { h->count[s] = info[s]; h->row_start[s] = info[kMaxSpecies + s]; }
   h->nrows = info[2 * kMaxSpecies];
@@ -582,7 +607,8 @@ int compute_mlp(ani_handle* h, hipStream_t st) {
                   h->mlp_chain <= 1;
   for (const auto& lp : layer_probs) {
     pipeline = pipeline && (int)lp.size() == np;
-    for (const GemmArgs& g : lp) pipeline = pipeline && g.N <= 256 && g.batch == 1;
+    for (const GemmArgs& g : lp)
+      pipeline = pipeline && g.N <= 256 && g.batch == 1 && (g.ldc & 31) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 127) == 0;
   }
   // without the pipeline the choice between chain and grouped launches is a matter of rounds (0.106 ms per chained round,
   // 0.137 ms per round of six grouped launches at the benchmark shapes)
@@ -690,6 +716,7 @@ int run_step64(ani_handle* h, const double* d_x, int eflag_atom, int vflag, doub
                   vflag ? h->virial_acc.p : nullptr, d_f, f_accumulate, d_ev, eflag_atom ? d_eatom : nullptr, h->err_flag.p, st);
   if (m.has_rep) launch_repulsion_energy(h->erep.p, kVirialSlots, d_ev, st);
   HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, take_launch_error());
   return ANI_OK;
 }
 
@@ -835,6 +862,7 @@ int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double
   step_finish(h, c, 0, h->ntotal, true, st);
   if (h->evt) HIP_TRY(h, hipEventRecord(h->evt[4], st));
   HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, take_launch_error());
   return ANI_OK;
 }
 
@@ -879,6 +907,13 @@ int finish_host(ani_handle* h, int ntotal, int nlocal, int eflag_atom, int vflag
   HIP_TRY(h, hipStreamSynchronize(st));
   if (flag) {
     HIP_TRY(h, hipMemsetAsync(h->err_flag.p, 0, sizeof(int), st));
+    h->sticky_flags |= flag;
+    if (flag & 2) {
+      // a wait between workgroups of the one-launch MLP ran into its bound: a forward-progress problem on the device, not
+      // a capacity problem -- no retry with larger lists
+      h->err = "a wait inside the one-launch MLP kernel timed out (device-side stall); results of this step are invalid";
+      return ANI_ERR_DEVICE;
+    }
     h->err = "an atom has more neighbours inside the radial/angular cutoff than the kernels' LDS capacity (radial: the "
              "longest list, or 3/4 of it unless option full_radial_capacity is set; angular: " + std::to_string(kMaxAng) + ")";
     return ANI_ERR_CAPACITY;
@@ -911,6 +946,11 @@ int ani_create(const char* model_file, int local_rank, int use_num_models, int u
     g_create_error = "cannot initialise HIP device " + std::to_string(h->device);
     delete h;
     return ANI_ERR_DEVICE;
+  }
+  // the reference's opt-in to reduced-precision products (LAMMPS_ANI_ALLOW_TF32, src/ani_csrc/ani.cpp:41-43): gfx950 has no
+  // TF32; the counterpart here is the two-term fp16 split (option "mlp_arith" 2), off unless asked for
+  if (const char* tf = getenv("LAMMPS_ANI_ALLOW_TF32")) {
+    if (tf[0] && strcmp(tf, "0") != 0) h->mlp_arith = MLP_F16X2;
   }
   int rc = upload_model(h);
   if (rc != ANI_OK) { g_create_error = h->err; ani_destroy(h); return rc; }
@@ -992,6 +1032,10 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
     HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, d_numneigh, sizeof(int) * (size_t)nlocal, hipMemcpyDeviceToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->jraw.p, d_jlist, sizeof(int) * (size_t)npairs, hipMemcpyDeviceToDevice, st));
     h->have_list = false;
+    // A device-resident caller cannot be handed ANI_ERR_CAPACITY and retried (nothing synchronises; the energy turns NaN
+    // and a loop notices steps later): the radial lists get the capacity of the longest candidate list from the start.
+    // (The 3/4 estimate of the host entry points saves LDS only; they repeat the step when it was too small.)
+    h->ap.full_cap = h->ap_run.full_cap = 1;
     rc = rebuild(h, st);
     if (rc) return rc;
     h->have_list = true;
@@ -1031,6 +1075,7 @@ int ani_step_begin(ani_handle* h, int ntotal, int nlocal, const double* d_x, int
   rc = step_compact_forward(h, step_aev_args(h, c, 2), st);
   if (rc) { h->split_phase = 0; return rc; }
   HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, take_launch_error());
   return ANI_OK;
 }
 
@@ -1069,6 +1114,7 @@ int ani_step_ghosts_ready(ani_handle* h, void* stream) {
   if (rc) { h->split_phase = 0; return rc; }
   HIP_TRY(h, hipEventRecord(h->ev_side, h->side));
   HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, take_launch_error());
   return ANI_OK;
 }
 
@@ -1084,6 +1130,7 @@ int ani_step_finish(ani_handle* h, void* stream) {
   HIP_TRY(h, hipStreamWaitEvent(st, h->ev_side, 0));   // the backward pass launched by ani_step_ghosts_ready on the side stream
   step_finish(h, c, 0, h->nlocal, true, st);
   HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, take_launch_error());
   if (h->profiling) HIP_TRY(h, hipStreamSynchronize(st));
   return ANI_OK;
 }
@@ -1137,6 +1184,7 @@ int build_list(ani_handle* h, int ntotal, int nlocal, const int* d_species, cons
   HIP_TRY(h, h->jraw.reserve(total));
   launch_nbr_fill(nlocal, ntotal, g, s, cutneigh, h->nbr_off.p, h->jraw.p, h->ilist.p, st);
   HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, take_launch_error());
   rc = rebuild(h, st);
   if (rc) return rc;
   h->have_list = true;
@@ -1162,6 +1210,7 @@ int ani_build_list_device(ani_handle* h, int ntotal, int nlocal, const int* d_sp
   const int rc = build_list_args(h, ntotal, nlocal, d_species, d_x, cutneigh, lo, hi, "ani_build_list_device");
   if (rc) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
+  h->ap.full_cap = h->ap_run.full_cap = 1;   // device-resident callers: see ani_compute_full_device
   return build_list(h, ntotal, nlocal, d_species, d_x, cutneigh, lo, hi, out_npairs, (hipStream_t)stream);
 }
 
@@ -1272,6 +1321,13 @@ int ani_debug_get(ani_handle* h, ani_debug_view* out) {
   out->nlocal = h->nlocal; out->ntotal = h->ntotal; out->nrows = h->nrows; out->npairs = h->npairs;
   out->d_aev = h->aev.p; out->d_gaev = h->gaev.p; out->d_row_of_centre = h->row_of_centre.p;
   out->aev_stride = h->ap_run.aev_stride; out->aev_active_length = h->ap_run.aev_len;
+  if (h->err_flag.p) {   // a diagnostics call: wait for whatever is queued on the device, then read the word as it stands
+    int flag = 0;
+    if (hipSetDevice(h->device) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(&flag, h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess)
+      h->sticky_flags |= flag;
+  }
+  out->error_flags = h->sticky_flags;
   for (int s = 0; s < kMaxSpecies && s < 16; s++) out->species_count[s] = h->count[s];
   return ANI_OK;
 }

@@ -17,6 +17,12 @@ constexpr int kVirialSlots = 1024;  // rows of 9 doubles the waves of the AEV ba
 
 enum Epilogue { EPI_PLAIN = 0, EPI_CELU = 1, EPI_LAST = 2, EPI_BWD = 3 };
 
+// The launch wrappers below return void; a failing HIP call inside one (a memset, a function attribute) is noted here and
+// the entry point that issued the work reports it (take_launch_error() returns the first failure since the last take and
+// clears it).  One collector per host thread: a handle is driven from one thread at a time (include/ani_hip.h).
+void note_launch_error(hipError_t e);
+hipError_t take_launch_error();
+
 // C[rows][N] = epi( A[rows][K] * Bt[N][K]^T ), fp32 MFMA.  Batched over blockIdx.y (ensemble members).
 struct GemmArgs {
   const float* A;

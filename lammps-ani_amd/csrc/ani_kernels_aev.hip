@@ -1472,7 +1472,7 @@ static void launch_fast(K kernel, const AevParams& p, const AevArgs& a, int wave
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mtx);
     if (raised.insert(std::make_pair(dev, (const void*)kernel)).second)
-      (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      note_launch_error(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   hipLaunchKernelGGL(kernel, dim3(persistent_blocks(kernel, a.kcount, waves, lds)), dim3(64 * waves), lds, st, p, a, cap, rowf,
                      extra...);

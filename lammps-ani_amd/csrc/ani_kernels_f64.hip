@@ -357,7 +357,7 @@ void launch_gemm64(const Gemm64Args& g, Epilogue epi, hipStream_t st) {
 void launch_finish64(const double* e_rows, int M, int nrows, const int* centre_of_row, const int* ilist, const int* species,
                      const Sae64& sae, const double* fbuf, int ntotal, const double* vir, double* f_out, int accumulate, double* ev,
                      double* eatom, const int* err_flag, hipStream_t st) {
-  (void)hipMemsetAsync(ev, 0, sizeof(double) * 10, st);
+  note_launch_error(hipMemsetAsync(ev, 0, sizeof(double) * 10, st));
   hipLaunchKernelGGL(finish64_energy, dim3(64), dim3(256), 0, st, e_rows, M, nrows, centre_of_row, ilist, species, sae, eatom, ev);
   const int n3 = ntotal * 3 > 9 ? ntotal * 3 : 9;
   hipLaunchKernelGGL(finish64_rest, dim3((n3 + 255) / 256), dim3(256), 0, st, fbuf, ntotal * 3, f_out, accumulate, vir, ev, err_flag);

@@ -190,9 +190,9 @@ void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numne
   int* rank = o.row_of_centre + nlocal;
   int* chunk_tot = o.row_of_centre + 2 * (size_t)nlocal;
   const int nchunks = nlocal / kPrepChunk + 1;
-  (void)hipMemsetAsync(o.centre_of_row, 0xff, sizeof(int) * (size_t)nrows_cap, st);
-  (void)hipMemsetAsync(o.row_info, 0xff, sizeof(int4) * (size_t)nrows_cap, st);
-  (void)hipMemsetAsync(o.bucket_info, 0, sizeof(int) * kBucketInfoInts, st);
+  note_launch_error(hipMemsetAsync(o.centre_of_row, 0xff, sizeof(int) * (size_t)nrows_cap, st));
+  note_launch_error(hipMemsetAsync(o.row_info, 0xff, sizeof(int4) * (size_t)nrows_cap, st));
+  note_launch_error(hipMemsetAsync(o.bucket_info, 0, sizeof(int) * kBucketInfoInts, st));
   hipLaunchKernelGGL(prepare_count_kernel, dim3(nchunks), dim3(1024), 0, st, d_species, d_ilist, d_numneigh, nlocal, ntotal, S, o,
                      rank, chunk_tot);
   hipLaunchKernelGGL(prepare_rows_kernel, dim3(nlocal > 0 ? (nlocal + 255) / 256 : 1), dim3(256), 0, st, d_species, d_ilist,
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(1024) void partition_rows_kernel(const int* __restr
 }
 
 void launch_row_classes(const int4* row_info, const int* jlist, int nrows, int nlocal, int* flag, int* list, int* count, hipStream_t st) {
-  if (nrows <= 0) { (void)hipMemsetAsync(count, 0, sizeof(int), st); return; }
+  if (nrows <= 0) { note_launch_error(hipMemsetAsync(count, 0, sizeof(int), st)); return; }
   hipLaunchKernelGGL(classify_rows_kernel, dim3((nrows + 3) / 4), dim3(256), 0, st, row_info, jlist, nrows, nlocal, flag);
   hipLaunchKernelGGL(partition_rows_kernel, dim3(1), dim3(1024), 0, st, flag, nrows, list, count);
 }

@@ -770,10 +770,14 @@ __global__ __launch_bounds__(256, 3) void mlp_pipeline_x2(const GemmArgs* __rest
         int spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 21)) __builtin_amdgcn_s_sleep(16);
         if (spins >= (1 << 21)) atomicOr(err_flag, 2);
+        // ONE agent-scope acquire after the poll has matched (buffer_inv sc1: drops this CU's L1 lines, whatever touched them
+        // earlier in the launch), waited for before the barrier releases the other waves' loads
+        // (cdna_hip_programming.md, Guideline 16).  The producer side needs no release fence: every result was stored
+        // write-through (sc1) and acknowledged (s_waitcnt 0 in every storing wave, then the barrier) before the flag.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();
-      // the producer's stores went to memory and this XCD has never read these lines: only this CU's L1 is told
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     const GemmArgs g = layers[l * nprob + pi];
     const int e = epi[l];
@@ -905,6 +909,14 @@ hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers,
   }
   const unsigned char* d = reinterpret_cast<const unsigned char*>(plan->d_desc);
   if (pipeline) {
+    // The hand-off between workgroups is per 64-row tile of C: no 128-byte line may hold rows of two tiles, or a consumer
+    // could keep a line that a second producer completes later.  Row strides that are multiples of 32 floats on 128-byte
+    // aligned bases guarantee it; the caller (compute_mlp) selects this path only then, and it is checked again here.
+    for (int i = 0; i < nlayers * nprob; i++) {
+      const GemmArgs& g = layers[i];
+      if ((g.ldc & 31) || (reinterpret_cast<uintptr_t>(g.C) & 127) || (g.lda & 3) || (reinterpret_cast<uintptr_t>(g.A) & 15))
+        return hipErrorInvalidValue;
+    }
     const size_t nitems = (size_t)nlayers * total, nflags = nitems + 8;   // + the item counters
     if (plan->done_n < nflags) {
       if (plan->d_done) (void)hipFree(plan->d_done);

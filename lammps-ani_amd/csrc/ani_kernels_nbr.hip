@@ -196,10 +196,10 @@ __global__ void iota_kernel(int* __restrict__ out, int n) {
 }  // namespace
 
 void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrScratch& s, hipStream_t st) {
-  (void)hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(g.ncell + 1), st);
-  (void)hipMemsetAsync(s.cursor, 0, sizeof(int) * (size_t)g.ncell, st);
+  note_launch_error(hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(g.ncell + 1), st));
+  note_launch_error(hipMemsetAsync(s.cursor, 0, sizeof(int) * (size_t)g.ncell, st));
   if (ntotal <= 0) {
-    (void)hipMemsetAsync(s.cell_start, 0, sizeof(int) * (size_t)(g.ncell + 1), st);
+    note_launch_error(hipMemsetAsync(s.cell_start, 0, sizeof(int) * (size_t)(g.ncell + 1), st));
     return;
   }
   const dim3 grid((ntotal + 255) / 256), block(256);

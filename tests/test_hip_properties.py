@@ -124,8 +124,8 @@ def test_argument_errors(model_cache, hip):
 
 
 def test_split_mlp_arithmetics_are_as_accurate_as_fp32_input_mfma(model_cache, hip):
-    """The MLP evaluates its fp32 products on the 16-bit MFMA pipe (option mlp_arith): 2 (default) = three fp16 products of
-    two-term splits of the power-of-two scaled operands (operands good to 2^-22), 1 = six bf16 products of the exact
+    """The MLP evaluates its fp32 products on the 16-bit MFMA pipe (option mlp_arith): 2 (opt-in) = three fp16 products of
+    two-term splits of the power-of-two scaled operands (operands good to 2^-22), 1 (default) = six bf16 products of the exact
     three-term splits, 0 = the fp32-input MFMA instruction.  Against the fp64 oracle each split path must be as good as
     the fp32-input one -- forces AND per-atom energies, max and rms -- and all must agree with each other far inside the
     force tolerance; water with one member (chained launch and per-layer launches) and the full 8-member ensemble on a
@@ -270,6 +270,7 @@ def test_mlp_pipeline_equals_per_layer_launches_on_changing_inputs(natoms, model
     piped, layered = hip.ANI(p, 0), hip.ANI(p, 0)
     for h, v in ((piped, 2), (layered, 0)):
         h.set_option("mlp_chain", 0)
+        h.set_option("mlp_arith", 2)      # the one-launch pipeline exists for the two-term arithmetic (an opt-in since round 3)
         h.set_option("mlp_pipeline", v)
     rng = np.random.default_rng(3)
     direction = rng.normal(size=(inp.nlocal, 3))
