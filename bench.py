@@ -269,7 +269,9 @@ def main():
             ref = Oracle(path).compute(inp, radial_compat=(args.aev == "pyaev"))
             fr = ref["force"][: inp.nlocal].copy()
             np.add.at(fr, inp.owner_lidx, ref["force"][inp.nlocal:])
+            run._forces()                 # the pair style's forces alone (set-up had already added the thermostat's share)
             f0 = run.f[: run.nlocal].cpu().numpy()
+            run._post_force()             # ... which is put back before the first step integrates
             err = np.abs(f0 - fr)
             parity = {"max_abs_force_err_kcal_mol_A": float(err.max()), "rms_force_err": float(np.sqrt((err ** 2).mean())),
                       "max_abs_force": float(np.abs(fr).max()),
@@ -306,28 +308,25 @@ def main():
         if parity:
             info["parity_md_model"] = parity
         if measure_rebuilds:
-            # untimed continuation: blocks of `every` steps, each bracketed by a synchronisation; a block that re-neighbours
-            # against the ones that do not gives the surcharge of a rebuild step, the count gives the interval
-            blk, plain, heavy, nb_seen, nsteps_seen = run.every, [], [], run.nbuilds - b0, steps
-            for _ in range(80):
-                if len(heavy) >= 3 and len(plain) >= 3:
-                    break
-                nb, tb = run.nbuilds, time.perf_counter()
-                for _ in range(blk):
+            # untimed continuation, without a break in the loop: on until it has re-neighboured three times (at least 100
+            # steps, at most 600).  Its rate is the loop's rate whatever K was; with the K-step window it also gives the cost
+            # of a plain step and the surcharge of a re-neighbouring step (two windows, two unknowns).
+            nb0, n_post, t1 = run.nbuilds, 0, time.perf_counter()
+            while n_post < 600 and (run.nbuilds - nb0 < 3 or n_post < 100):
+                for _ in range(run.every):
                     run.step()
-                sync_all()
-                tblk = max_over_ranks(time.perf_counter() - tb)
-                (heavy if run.nbuilds > nb else plain).append((tblk, run.nbuilds - nb))
-                nb_seen += run.nbuilds - nb
-                nsteps_seen += blk
-            info["post_run_steps"] = nsteps_seen - steps
-            if plain:
-                t_plain = float(np.median([t for t, _ in plain])) / blk * 1e3
-                info["plain_ms_per_step"] = t_plain
-                if heavy:
-                    info["rebuild_ms"] = float(np.mean([(t * 1e3 - t_plain * blk) / n for t, n in heavy]))
-                    info["rebuild_interval_steps"] = nsteps_seen / max(nb_seen, 1)
-                    info["amortised_ms_per_step"] = t_plain + info["rebuild_ms"] / info["rebuild_interval_steps"]
+                n_post += run.every
+            sync_all()
+            t_post = max_over_ranks(time.perf_counter() - t1)
+            r1, r2 = info["list_rebuilds"], run.nbuilds - nb0
+            info["long_window"] = {"steps": n_post, "list_rebuilds": r2, "ms_per_step": t_post / n_post * 1e3}
+            if r2 > 0:
+                info["amortised_ms_per_step"] = t_post / n_post * 1e3
+                info["rebuild_interval_steps"] = (steps + n_post) / (r1 + r2)
+                det = steps * r2 - n_post * r1
+                if det != 0:
+                    info["plain_ms_per_step"] = (dt * r2 - t_post * r1) / det * 1e3
+                    info["rebuild_ms"] = (steps * t_post - n_post * dt) / det * 1e3
             info["energy_finite"] = info["energy_finite"] and bool(np.isfinite(run.potential_energy()))
         view = ani.debug_view()
         ani.close()
@@ -380,8 +379,8 @@ def main():
                 md_info["timed_region_ms_per_step"], md_info["timed_region_value"] = ms_per_step, ns_day
                 ms_per_step = md_info["amortised_ms_per_step"]
                 ns_day = 0.0432 / (ms_per_step * 1e-3)
-                value_basis = ("the K timed steps contained no re-neighbouring: value = 1 / (plain step + rebuild surcharge / rebuild "
-                               "interval), all three measured in this run (md_loop.plain_ms_per_step, rebuild_ms, rebuild_interval_steps)")
+                value_basis = ("the K timed steps contained no re-neighbouring and would overstate the loop: value is the rate of the longer "
+                               "window that follows them in the same run, re-neighbourings included (md_loop.long_window)")
         if phases["calls"] == 0:   # the cut step of the overlapped exchange records no phase events: the hot-path pass has them
             phases = ph_hot
         calls = max(phases["calls"], 1)

@@ -31,7 +31,16 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in d["cpu_baseline"], k
     assert d["parity"]["max_abs_force_err_kcal_mol_A"] < 2.3e-3
     # the headline is the MD loop (integration, re-neighbouring, ghost exchange, hot path), the hot path alone is secondary
-    assert d["md_loop"]["steps"] == 8 and abs(d["md_loop"]["ms_per_step"] - d["ms_per_step"]) < 1e-9
+    # ... timed over exactly K steps; a window without a re-neighbouring does not become the headline: the rate of the longer
+    # window that follows it (re-neighbourings included) does
+    md = d["md_loop"]
+    assert md["steps"] == 8 and "value_basis" in d
+    if md["list_rebuilds"] > 0 or "amortised_ms_per_step" not in md:
+        assert abs(md["ms_per_step"] - d["ms_per_step"]) < 1e-9
+    else:
+        assert abs(md["amortised_ms_per_step"] - d["ms_per_step"]) < 1e-9 and md["long_window"]["list_rebuilds"] > 0
+        assert abs(md["timed_region_ms_per_step"] - md["ms_per_step"]) < 1e-9
+    assert md["parity_md_model"]["max_abs_force_err_kcal_mol_A"] < 2.3e-3
     assert "MD ns/day" in d["metric"] and d["hot_path"]["value"] > 0
     assert abs(d["value"] - 0.0432 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "median of 3" in d["cpu_baseline"]["sample"]
