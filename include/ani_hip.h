@@ -193,8 +193,13 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *       nor as neighbour) are identically zero; with 1 the kernels work on the remaining columns only (ANI-2x water:
  *       128 of 1008) and the first-layer products use the matching weight columns — the same sums without the zero
  *       terms.  0 forces the full 1008-column layout.
- *   "mlp_arith" (default 2): how the MLP evaluates its fp32 products; fp32 accumulation in every case, takes effect at
- *       the next call.
+ *   "mlp_fused" (default 1): networks of three hidden layers (every ANI-1x / ANI-2x member) run as ONE launch in which a
+ *       workgroup takes a 128-row tile through all six products of every member with the activations in registers
+ *       (ani_kernels_mlpf.hip); HBM sees the AEV rows and the dE/dAEV rows only.  0 = the per-layer kernels below.  Needs a
+ *       split arithmetic ("mlp_arith" 1 or 2).  Takes effect at the next call.
+ *   "mlp_arith" (default 1): how the MLP evaluates its fp32 products; fp32 accumulation in every case, takes effect at
+ *       the next call.  1, the exact split, is what the reference's "fp32 with TF32 off" means on this chip; 2 is the
+ *       counterpart of its opt-in LAMMPS_ANI_ALLOW_TF32 (src/ani_csrc/ani.cpp:41-43), also selected by that variable.
  *         2 = three v_mfma_f32_32x32x16_f16 products of two-term fp16 splits: every operand, scaled by a power of two
  *             (weights so that a layer's largest sits below 2^13, activations by 2^4, gradients by 2^12; undone exactly on
  *             the accumulators), is h + l with two fp16 numbers rounded to nearest -- good to 2^-22 relative (fp32: 2^-24)
@@ -203,14 +208,14 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *             of the step is the AEV's fp32 arithmetic; bench.py "parity", tests/test_hip_properties.py).  An activation
  *             beyond 4094 or a gradient beyond 16 Hartree per unit overflows fp16: inf, NaN energy, reported -- not wrong.
  *         1 = six v_mfma_f32_32x32x16_bf16 products of the EXACT three-term bf16 splits (8+8+8 mantissa bits) of both
- *             operands; the three dropped terms are below 2^-23 of the product: one fp32 rounding.  1.26x the MLP time of 2.
+ *             operands; the three dropped terms are below 2^-23 of the product: one fp32 rounding.
  *         0 = the fp32-input instruction v_mfma_f32_32x32x2_f32 (1/16 of the 16-bit matrix rate on gfx950).
  *   "mlp_split_bf16": earlier name; 1 selects "mlp_arith" 1, 0 selects "mlp_arith" 0.
- *   "mlp_pipeline" (default 1): with one ensemble member, the default arithmetic, layers no wider than 256 and more 64-row
+ *   "mlp_pipeline" (default 1; per-layer kernels only): with one ensemble member, arithmetic 2, layers no wider than 256 and more 64-row
  *       tiles than one round of chained workgroups (about 32 000 water atoms) the six MLP products run as ONE launch of
  *       persistent workgroups that walk (layer, tile) items in order, each waiting for the flag of the same rows' item
  *       of the layer before; 2 = at any size (measurement knob), 0 = never.  Takes effect at the next call.
- *   "mlp_chain" (default 1): with one ensemble member and few row tiles (small systems) the six MLP products run as one
+ *   "mlp_chain" (default 1; per-layer kernels only): with one ensemble member and few row tiles (small systems) the six MLP products run as one
  *       chained launch instead of six grouped ones; 2 = at any size (measurement knob), 0 = never.  Takes effect at the
  *       next call.
  *   "device_overwrite_forces" (default 0): ani_compute_full_device ADDS forces into d_f like the reference's Kokkos
@@ -235,6 +240,10 @@ int ani_set_option(ani_handle* h, const char* name, int value);
 void ani_trace_push(const char* name);
 void ani_trace_pop(void);
 void ani_trace_mark(const char* name);
+
+/* development probe: per-phase cycle counters of a diagnostic (-DABLF_STAMPS) build of the fused MLP kernel
+ * (tools/mlpf_stamps.py); returns 0 and writes nothing in the shipped build */
+int ani_debug_fused_stamps(unsigned long long* out16, int reset);
 
 /* copy `bytes` from a device pointer of the view to host memory (synchronises the handle's stream first) */
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes);

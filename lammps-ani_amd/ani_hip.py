@@ -21,7 +21,8 @@ HARTREE2KCALMOL = 627.5094738898777
 EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani_use_num_models", "ani_num_species",
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
            "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times",
-           "ani_trace_push", "ani_trace_pop", "ani_trace_mark", "ani_step_begin", "ani_step_ghosts_ready", "ani_step_finish"]
+           "ani_trace_push", "ani_trace_pop", "ani_trace_mark", "ani_step_begin", "ani_step_ghosts_ready", "ani_step_finish",
+           "ani_debug_fused_stamps"]
 
 
 class AniError(RuntimeError):

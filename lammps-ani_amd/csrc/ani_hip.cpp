@@ -93,6 +93,15 @@ struct SpeciesNet {
     unsigned short *W0c = nullptr, *WT0c = nullptr;
   } sp[2];
   std::vector<float> wscale;   // [L-1] power of two that brings the largest |weight| of layer k (all members) below 2^13
+  // the fused one-workgroup-per-tile MLP (ani_kernels_mlpf.hip): weight stream and constants per split arithmetic
+  // ([0] three bf16 planes, [1] two fp16 planes), built for the AEV layout of the epoch (fused_mask)
+  struct Fused {
+    unsigned char* stream = nullptr;
+    float* consts = nullptr;
+    long long ppm = 0;   // pieces per member
+    int cpm = 0;         // constants (floats) per member
+  } fu[2];
+  int fused_shape = -1;
 };
 inline MlpArith planes_arith(int i) { return i == 0 ? MLP_BF16X3 : MLP_F16X2; }
 
@@ -107,6 +116,10 @@ struct ani_handle {
   bool prune = true;  // ani_set_option("prune_absent_species")
   int mlp_pipeline = 1;   // ani_set_option("mlp_pipeline"): 1 = large systems run all MLP layers as one launch of persistent workgroups
                           // with per-tile dependencies, 2 = at any size (measurement knob), 0 = one launch per layer
+  int mlp_fused = 1;   // ani_set_option("mlp_fused"): 1 = networks of three hidden layers run as one launch, a 128-row tile per
+                       // workgroup with the activations in registers (ani_kernels_mlpf.hip); 0 = the per-layer kernels
+  int fused_mask[2] = {-2, -2};   // active_mask the fused streams of each arithmetic were built for
+  DevBuf<int> fused_counter;
   int mlp_chain = 1;   // ani_set_option("mlp_chain"): 1 = one chained launch for the MLP of small systems, 2 = at any size, 0 = never
   ChainPlan chain_plan;
   bool profiling = false;  // ani_set_option("profiling"): every entry point synchronises its stream before returning
@@ -489,12 +502,136 @@ int rebuild(ani_handle* h, hipStream_t st) {
   return ANI_OK;
 }
 
+// ---- fused MLP: eligibility, stream construction, launch ---------------------------------------------------------
+bool fused_eligible(const ani_handle* h) {
+  const HostModel& m = h->model;
+  if (!h->mlp_fused || h->mlp_arith == MLP_FP32 || m.L != 4) return false;
+  const int acols = h->ap_run.aev_len;
+  if (acols < 16 || (acols & 15) || (h->ap_run.aev_stride & 3)) return false;
+  for (int s = 0; s < m.S; s++)
+    if (fused_shape_for(m.dims[s][1], m.dims[s][2], m.dims[s][3]) < 0 || m.dims[s][4] != 1) return false;
+  return true;
+}
+
+void free_fused(ani_handle* h, int pi) {
+  for (auto& n : h->nets) {
+    if (n.fu[pi].stream) (void)hipFree(n.fu[pi].stream);
+    if (n.fu[pi].consts) (void)hipFree(n.fu[pi].consts);
+    n.fu[pi] = SpeciesNet::Fused{};
+  }
+  h->fused_mask[pi] = -2;
+}
+
+// weight streams + constants of every species for arithmetic `arith`, in the AEV layout of this epoch
+int ensure_fused(ani_handle* h, MlpArith arith, hipStream_t st) {
+  const int pi = arith == MLP_F16X2 ? 1 : 0, P = mlp_planes(arith);
+  if (h->fused_mask[pi] == h->active_mask) return ANI_OK;
+  free_fused(h, pi);
+  const HostModel& m = h->model;
+  const int M = m.M, acols = h->ap_run.aev_len, ka = h->ap_run.aev_stride;
+  const int ks0 = acols / 16, nt0 = (acols + 31) / 32;
+  for (int s = 0; s < m.S; s++) {
+    SpeciesNet& n = h->nets[s];
+    const std::vector<int>& d = m.dims[s];
+    const int shape = fused_shape_for(d[1], d[2], d[3]);
+    n.fused_shape = shape;
+    int nt[3];
+    fused_shape_tiles(shape, nt);
+    SpeciesNet::Fused& f = n.fu[pi];
+    f.ppm = fused_pieces_per_member(shape, acols, P);
+    f.cpm = fused_consts_floats(shape);
+    HIP_TRY(h, hipMalloc((void**)&f.stream, (size_t)f.ppm * M * 1024));
+    HIP_TRY(h, hipMalloc((void**)&f.consts, sizeof(float) * (size_t)f.cpm * M));
+    std::vector<float> cst((size_t)f.cpm * M, 0.f);
+    for (int a = 0; a < M; a++) {
+      unsigned short* dst = reinterpret_cast<unsigned short*>(f.stream + (size_t)a * f.ppm * 1024);
+      auto emit = [&](const float* src, int ld, int rows, int kval, int NT, int KS, int chunk, float scale) {
+        launch_build_stream(src, ld, rows, kval, NT, KS, chunk, P, scale, dst, st);
+        dst += (size_t)NT * KS * P * 512;
+      };
+      const float ws0 = n.wscale[0], ws1 = n.wscale[1], ws2 = n.wscale[2];
+      emit((n.W0c ? n.W0c : n.W[0]) + (size_t)a * d[1] * ka, ka, d[1], acols, nt[0], ks0, 0, ws0);                 // F1
+      emit(n.W[1] + (size_t)a * d[2] * n.w[1], n.w[1], d[2], d[1], nt[1], 2 * nt[0], 0, ws1);                       // F2
+      emit(n.W[2] + (size_t)a * d[3] * n.w[2], n.w[2], d[3], d[2], nt[2], 2 * nt[1], 0, ws2);                       // F3
+      emit(n.WT[2] + (size_t)a * d[2] * n.w[3], n.w[3], d[2], d[3], nt[1], 2 * nt[2], -1, ws2);                     // B3
+      emit(n.WT[1] + (size_t)a * d[1] * n.w[2], n.w[2], d[1], d[2], nt[0], 2 * nt[1], -1, ws1);                     // B2
+      emit((n.WT0c ? n.WT0c : n.WT[0]) + (size_t)a * n.w[1], M * n.w[1], acols, d[1], nt0, 2 * nt[0], 4, ws0);      // B1 (chunks of kChunk tiles)
+      if ((size_t)(dst - reinterpret_cast<unsigned short*>(f.stream + (size_t)a * f.ppm * 1024)) != (size_t)f.ppm * 512) {
+        h->err = "internal: fused MLP stream size mismatch";
+        return ANI_ERR_MODEL;
+      }
+      float* c = cst.data() + (size_t)a * f.cpm;
+      int off = 0;
+      for (int o = 0; o < d[1]; o++) c[off + o] = m.b[a][s][0][o];
+      off += 32 * nt[0];
+      for (int o = 0; o < d[2]; o++) c[off + o] = m.b[a][s][1][o];
+      off += 32 * nt[1];
+      for (int o = 0; o < d[3]; o++) c[off + o] = m.b[a][s][2][o];
+      off += 32 * nt[2];
+      for (int o = 0; o < d[3]; o++) c[off + o] = m.W[a][s][3][o];
+      off += 32 * nt[2];
+      c[off] = m.b[a][s][3][0];
+      const bool f16 = arith == MLP_F16X2;
+      c[off + 1] = f16 ? 1.f / (16.f * ws0) : 1.f;
+      c[off + 2] = f16 ? 1.f / (16.f * ws1) : 1.f;
+      c[off + 3] = f16 ? 1.f / (16.f * ws2) : 1.f;
+      c[off + 4] = f16 ? 1.f / (4096.f * ws2) : 1.f;
+      c[off + 5] = f16 ? 1.f / (4096.f * ws1) : 1.f;
+      c[off + 6] = f16 ? 1.f / (4096.f * ws0) : 1.f;
+    }
+    HIP_TRY(h, hipMemcpyAsync(f.consts, cst.data(), sizeof(float) * cst.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipStreamSynchronize(st));   // cst is a local
+  }
+  HIP_TRY(h, hipGetLastError());
+  h->fused_mask[pi] = h->active_mask;
+  return ANI_OK;
+}
+
+int compute_mlp_fused(ani_handle* h, hipStream_t st) {
+  const HostModel& m = h->model;
+  const MlpArith arith = h->mlp_arith;
+  const int pi = arith == MLP_F16X2 ? 1 : 0;
+  int rc = ensure_fused(h, arith, st);
+  if (rc) return rc;
+  HIP_TRY(h, h->fused_counter.reserve(1));
+  FusedArgs G{};
+  G.M = m.M; G.alpha = (float)m.alpha; G.inv_alpha = (float)(1.0 / m.alpha); G.scale = 1.f / (float)m.M;
+  G.counter = h->fused_counter.p;
+  const int acols = h->ap_run.aev_len, ka = h->ap_run.aev_stride;
+  int np = 0, total = 0;
+  for (int shape = 0; shape < 3; shape++)        // costliest species first
+    for (int s = 0; s < m.S; s++) {
+      const SpeciesNet& n = h->nets[s];
+      if (h->count[s] == 0 || n.fused_shape != shape) continue;
+      if (np == kMaxProblems) { h->err = "too many species buckets for one fused MLP launch"; return ANI_ERR_ARG; }
+      FusedProb& p = G.p[np];
+      p.aev = h->aev.p + (size_t)h->row_start[s] * ka;
+      p.gaev = h->gaev.p + (size_t)h->row_start[s] * ka;
+      p.e_rows = h->e_rows.p + h->row_start[s];
+      p.centre_of_row = h->centre_of_row.p + h->row_start[s];
+      p.stream = n.fu[pi].stream; p.consts = n.fu[pi].consts;
+      p.sE = h->nrows;
+      p.tiles = round_up(h->count[s], kRowTile) / kRowTile;
+      p.shape = shape;
+      p.ks0 = acols / 16; p.nt0 = (acols + 31) / 32; p.acols = acols; p.aev_stride = ka;
+      p.pieces_per_member = (int)n.fu[pi].ppm; p.consts_per_member = n.fu[pi].cpm;
+      G.tile_start[np] = total;
+      total += p.tiles;
+      np++;
+    }
+  G.tile_start[np] = total;
+  G.nprob = np;
+  HIP_TRY(h, launch_mlp_fused(G, arith, st));
+  return ANI_OK;
+}
+
 // The MLP ensemble for every species bucket, one grouped launch per layer (all species and members together).
 // Buffers of species s are local to the bucket (row 0 = row_start[s]).
 //   W[k]  : [M][d[k+1]][w[k]]   Bt of forward layer k (K = w[k], zero padded)
 //   WT[k] : [M][d[k]][w[k+1]]   Bt of the backward product through layer k (k >= 1);  WT[0]: [aev_len][M*w[1]]
 //   H_k   : [rows][M*w[k]]      activations after layer k-1 (member a at column a*w[k]); overwritten by G_k = dE/dz_k
 int compute_mlp(ani_handle* h, hipStream_t st) {
+  if (fused_eligible(h)) return compute_mlp_fused(h, st);
   const HostModel& m = h->model;
   const int L = m.L, M = m.M;
   const float alpha = (float)m.alpha, inv_alpha = (float)(1.0 / m.alpha);
@@ -997,6 +1134,8 @@ void ani_destroy(ani_handle* h) {
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();
+  free_fused(h, 0); free_fused(h, 1);
+  h->fused_counter.release();
   free_chain_plan(h->chain_plan);
   for (auto& e : h->evt_pool) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1358,6 +1497,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
     h->mlp_chain = value;
     return ANI_OK;
   }
+  if (strcmp(name, "mlp_fused") == 0) {
+    h->mlp_fused = value != 0;
+    return ANI_OK;
+  }
   if (strcmp(name, "mlp_pipeline") == 0) {
     if (value < 0 || value > 2) { h->err = "mlp_pipeline must be 0, 1 or 2"; return ANI_ERR_ARG; }
     h->mlp_pipeline = value;
@@ -1387,6 +1530,9 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   h->err = std::string("unknown option '") + name + "'";
   return ANI_ERR_ARG;
 }
+
+// development probe (tools/mlpf_stamps.py): phase cycle counters of a -DABLF_STAMPS build of the fused MLP; 0 otherwise
+int ani_debug_fused_stamps(unsigned long long* out16, int reset) { return fused_read_stamps(out16, reset); }
 
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes) {
   if (!h || !d_src || !host_dst) return ANI_ERR_ARG;

@@ -85,6 +85,45 @@ hipError_t launch_mlp_chain(const GemmArgs* layers, const int* epi, int nlayers,
 void free_chain_plan(ChainPlan& p);
 int mlp_chain_slots();   // workgroups the chain kernel can keep resident (2 per CU)
 
+// ---- the whole MLP of a row tile in one workgroup (ani_kernels_mlpf.hip) ----------------------------------------------
+// Networks with three hidden layers whose widths fit one of the compiled shapes (fused_shape_for >= 0), AEV width a multiple
+// of 16, split arithmetic.  Per species bucket: the weight stream (1 KB pieces in consumption order, members back to back:
+// fused_pieces_per_member each) and the constants block (fused_consts_floats floats per member: b0 | b1 | b2 | w3 padded to
+// the shape's tiles, then {b3, 1/scale of the six products, 0}).
+constexpr int kMaxProblems = 16;   // species buckets per launch
+struct FusedProb {
+  const float* aev;             // [rows][aev_stride] rows of the bucket
+  float* gaev;                  // [rows][aev_stride] dE/dAEV out
+  float* e_rows;                // member m's row energies at e_rows + m * sE
+  const int* centre_of_row;     // >= 0 for real rows
+  const unsigned char* stream;
+  const float* consts;
+  long long sE;
+  int tiles;                    // 128-row tiles
+  int shape;                    // index of the compiled shape
+  int ks0, nt0, acols, aev_stride;   // AEV: 16-column k-steps, 32-column tiles, columns in use, row stride
+  int pieces_per_member, consts_per_member;
+};
+struct FusedArgs {
+  FusedProb p[kMaxProblems];
+  int tile_start[kMaxProblems + 1];   // prefix of tiles per problem, costliest problems first
+  int nprob, M;
+  float alpha, inv_alpha, scale;      // CELU; scale = 1 / M
+  int* counter;                       // device word the workgroups draw tiles from (zeroed by the launcher)
+};
+int fused_shape_for(int d1, int d2, int d3);          // -1: no compiled shape holds these widths
+void fused_shape_tiles(int shape, int nt[3]);         // 32-feature tiles of the three hidden layers
+int fused_consts_floats(int shape);
+long long fused_pieces_per_member(int shape, int acols, int P);
+// one product's share of a stream: src[row][k] (ld) -> NT x KS blocks of P pieces at dst (see ani_kernels_mlpf.hip);
+// chunk: 0, -1 (tile-major: the hidden backward products) or 4 for the dE/dAEV product (the kernel walks four output tiles
+// at a time through all k-steps)
+void launch_build_stream(const float* src, int ld, int rows_valid, int k_valid, int NT, int KS, int chunk, int P, float scale,
+                         unsigned short* dst, hipStream_t st);
+hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st);
+// diagnostic builds (-DABLF_STAMPS) only: cycles per phase summed over tiles; returns 0 in the shipped build
+int fused_read_stamps(unsigned long long* out16, int reset);
+
 // dst[kb][N][planes][16] 16-bit planes of src[N][ld] (first K columns), kb = ceil(K/16); batch matrices src + i*s_src ->
 // dst + i*split_elems(N, K, arith).  scale: power of two applied to the weights of the fp16 path before they are split
 void launch_split_planes(const float* src, int batch, long long s_src, int N, int K, int ld, MlpArith arith, float scale,

@@ -1,0 +1,695 @@
+// ani_kernels_mlpf.hip — the whole MLP of a row tile in ONE workgroup, activations in registers (gfx950).
+//
+// Replaces, for the usual ANI networks (three hidden layers), the six grouped GEMM launches of ani_kernels_mlp.hip:
+// BmmEnsemble forward + energy shifter input + autograd back to dE/dAEV (reference call sites models/lammps_ani.py:110,
+// 228-230,197-206).  The six products of a member are still genuine dense contractions on the matrix pipe; what changes is
+// where their operands live.  The per-layer kernels wrote every activation to HBM only to read it back (1.1 GB per step at
+// 100 002 atoms, 3.9 TB/s, the MFMA pipe 16-23 % busy); here a 128-row species-pure tile is taken through
+//     h1 = celu(W0 aev + b0)  h2 = celu(W1 h1 + b1)  h3 = celu(W2 h2 + b2)  e = w3.h3 + b3
+//     g3 = w3 celu'(z3)/M     g2 = (W2^T g3) celu'(z2)   g1 = (W1^T g2) celu'(z1)   dE/dAEV = W0^T g1
+// by one workgroup of four waves, each wave owning 32 rows (atoms) for the whole pass.  HBM traffic of the MLP is then the
+// AEV rows in and the dE/dAEV rows out.
+//
+// Transposed formulation: every product is  X_out[features][atoms] = W[features][k] * X_in[k][atoms], the WEIGHTS the A
+// operand of v_mfma_f32_32x32x16_{bf16,f16}, the activations the B operand.  A 32x32 accumulator tile has its column (the
+// atom) on the lane and its rows (features) in the 16 registers, which is exactly the B-operand layout of the next
+// product's k-steps (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"): registers
+// 8s .. 8s+7 of tile t are the fragment of k-step 2t + s, element j of lane half h being feature
+//     kappa(ks, h, j) = 16 ks + 8 (j >> 2) + 4 h + (j & 3).
+// So an activation never leaves its lane: celu, the celu' masks of the backward pass, the split into 16-bit terms are
+// register arithmetic, and there is no barrier between layers.  The weights are permuted to match when the model is
+// uploaded (build_stream_kernel): the stream of a (species, member) is a sequence of 1 KB PIECES in exactly the order the
+// kernel consumes them -- piece (product, k-step, 32-row tile of outputs, plane) = the A fragment of one MFMA group, 16
+// bytes per lane -- which the four waves fetch round-robin with LDS-DMA (global_load_lds_dwordx4: 1 KB per instruction,
+// linear in LDS, no registers) into a ring of R pieces and all read back conflict-free (lane l reads bytes 16 l).
+// Arithmetic as in ani_kernels_mlp.hip (option mlp_arith): P = 3 exact three-term bf16 splits, six products; P = 2
+// two-term fp16 splits of scaled operands, three products.
+//
+// Synchronisation: a SLAB is the pieces of one k-step of one product.  Before a slab is consumed every wave waits (counted
+// vmcnt) for its own pieces of it, then one workgroup barrier says (a) everybody's pieces have landed and (b) everybody has
+// finished reading the slab before, whose ring space is refilled right behind the barrier.  One barrier per k-step
+// (~1 000-1 500 matrix-pipe cycles); loads run up to R pieces ahead of the consumer.
+//
+// Register budget (per lane, 512 with one wave per SIMD; largest shape): h1 128 + h2 96 + h3 80 = 304 at the end of the
+// forward pass; the backward products write each gradient over the activation it is masked with, their source held as
+// 16-bit fragments (g3: 120, g2: 144), so 128 + 96 + 120 + an accumulator while g2 is formed.  One workgroup per CU; tiles
+// are handed out from a counter, costliest species first.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
+#include <vector>
+
+#include "ani_kernels.h"
+#include "ani_mlp_common.h"
+
+namespace ani {
+
+#ifndef ANI_FUSED_RING
+#define ANI_FUSED_RING 128
+#endif
+constexpr int kRing = ANI_FUSED_RING;      // pieces (KB) in the LDS ring; power of two
+// timing-only ablation switches (wrong results): ABLF_NOWAIT no wait for the pieces of a slab, ABLF_NOBAR no barrier in
+// front of a slab, ABLF_NOMMA no MFMAs, ABLF_NODMA no weight loads
+constexpr int kConstBytes = 4096;          // LDS copy of a member's biases / output layer
+constexpr int kFusedLds = kRing * 1024 + kConstBytes;
+
+// diagnostic build (-DABLF_STAMPS): wave 0 of every workgroup adds the shader-clock cycles it spent in each phase of a tile
+// to g_fused_stamps (read by ani_debug_fused_stamps); no stamp executes in the shipped kernel
+#ifdef ABLF_STAMPS
+__device__ unsigned long long g_fused_stamps[16];
+#define FUSED_STAMP(k)                                                                       \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long _t;                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if (wave == 0 && lane == 0) atomicAdd(&g_fused_stamps[k], _t - stamp_prev);              \
+    stamp_prev = _t;                                                                         \
+  } while (0)
+#define FUSED_STAMP_INIT()                                                                   \
+  unsigned long long stamp_prev;                                                             \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+#else
+#define FUSED_STAMP(k) do {} while (0)
+#define FUSED_STAMP_INIT() do {} while (0)
+#endif
+
+// ---- weight stream of one product, in consumption order -------------------------------------------------------------
+// src[row][k] (ld elements per row): the A operand, rows = output features of the product, k = its contraction index.
+// Block b of the stream = (k-step ks, output tile nt): b = ks * NT + nt (forward products), b = nt * KS + ks (the two hidden
+// backward products) or, chunked (dE/dAEV: the kernel walks 8 tiles at a time through all k-steps), chunk-major.  Block b holds P pieces of 64 lanes x 8 16-bit elements:
+// lane l, element j  <-  src[32 nt + (l & 31)][kappa(ks, l >> 5, j)].
+__global__ void build_stream_kernel(const float* __restrict__ src, int ld, int rows_valid, int k_valid, int NT, int KS, int chunk,
+                                    int P, float scale, unsigned short* __restrict__ dst) {   // chunk < 0: tile-major blocks
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)NT * KS * 512;
+  if (idx >= total) return;
+  const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+  const int blk = (int)(idx >> 9);
+  int ks, nt;
+  if (chunk < 0) {        // b = nt * KS + ks: the backward products, one output tile through all its k-steps at a time
+    nt = blk / KS; ks = blk - nt * KS;
+  } else if (!chunk) {
+    ks = blk / NT; nt = blk - ks * NT;
+  } else {
+    int c = 0, rem = blk;
+    for (;;) {
+      const int ntc = min(chunk, NT - chunk * c);
+      if (rem < KS * ntc) { ks = rem / ntc; nt = chunk * c + (rem - ks * ntc); break; }
+      rem -= KS * ntc; c++;
+    }
+  }
+  const int row = 32 * nt + (lane & 31);
+  const int k = 16 * ks + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+  const float x = (row < rows_valid && k < k_valid) ? src[(long long)row * ld + k] : 0.f;
+  unsigned short* d = dst + ((long long)blk * P) * 512 + lane * 8 + j;
+  if (P == 3) {
+    unsigned h, m, l;
+    split3(x, h, m, l);
+    d[0] = (unsigned short)(h >> 16);
+    d[512] = (unsigned short)(m >> 16);
+    d[1024] = (unsigned short)(l >> 16);
+  } else {
+    unsigned h, l;
+    split2(x * scale, 0.f, h, l);
+    d[0] = (unsigned short)(h & 0xffffu);
+    d[512] = (unsigned short)(l & 0xffffu);
+  }
+}
+
+// ---- the ring -----------------------------------------------------------------------------------------------------------
+// A slab (the pieces of one k-step of a forward product, of one output tile of a hidden backward product) never wraps: a
+// slab that would cross the ring's end starts at its beginning instead, issuer and consumer applying the same rule to
+// the same sequence of slab sizes.  Inside a slab every fragment is then at a compile-time offset from one base address
+// (ds_read_b128 ... offset:imm): no address arithmetic per piece.
+struct Ring {
+  const unsigned char* src;   // the tile's weight stream (global), members back to back
+  int total;                  // pieces in it
+  int qi;                     // next piece of the stream to issue
+  int iseg, nseg;             // issuer: segment (see segment()) of the next slab to issue; segments per member
+  int ileft, isize;           // issuer: slabs left in that segment, pieces per slab of it
+  int vw;                     // issuer: virtual write position (pieces, skipped space included; position = vw mod kRing)
+  int vr;                     // consumer: virtual position of the slab being consumed
+  int own_issued, own_needed; // pieces this wave has issued / that the slabs consumed so far needed from this wave
+  int ks0, nt0;               // AEV k-steps / dE/dAEV tiles of the problem (the slab sequence depends on them)
+};
+
+__device__ __forceinline__ void wait_vmcnt_le(int c) {
+  // "all but the c youngest vector-memory operations of this wave are done".  Rounded down to one of four immediates
+  // (waiting for a few more pieces, issued at least a slab ago, costs nothing; a long chain of cases did); younger loads /
+  // stores of other kinds only make the wait more conservative.
+  if (c >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (c >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (c >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// pieces k = wave, wave + 4, ... < n of a slab: this wave's share
+__device__ __forceinline__ int own_share(int n, int wave) { return (n - wave + 3) >> 2; }
+
+// A member's slabs come in SEGMENTS of equal slabs:  F1 ks0 x [NT1]  F2 2NT1 x [NT2]  F3 2NT2 x [NT3]  B3 NT2 x [2NT3]
+// B2 NT1 x [2NT2]  then per chunk of kChunk dE/dAEV tiles 2NT1 x [tiles of the chunk]   (sizes times P).  The issuer looks a
+// segment up when it enters it, not per slab.
+constexpr int kChunk = 4;   // dE/dAEV tiles walked together through all k-steps (accumulators: 16 registers each)
+template <int NT1, int NT2, int NT3, int P>
+__device__ __forceinline__ void segment(int seg, int ks0, int nt0, int& count, int& size) {
+  if (seg == 0) { count = ks0; size = NT1 * P; }
+  else if (seg == 1) { count = 2 * NT1; size = NT2 * P; }
+  else if (seg == 2) { count = 2 * NT2; size = NT3 * P; }
+  else if (seg == 3) { count = NT2; size = 2 * NT3 * P; }
+  else if (seg == 4) { count = NT1; size = 2 * NT2 * P; }
+  else { count = 2 * NT1; size = min(kChunk, nt0 - kChunk * (seg - 5)) * P; }
+}
+
+// refill: every whole slab that fits behind the consumer
+template <int NT1, int NT2, int NT3, int P>
+__device__ __forceinline__ void ring_issue(Ring& r, unsigned char* ring, int wave, int lane16) {
+  while (r.qi < r.total) {
+    const int n = r.isize;
+    const int pw = r.vw & (kRing - 1);
+    const int vws = pw + n > kRing ? r.vw + (kRing - pw) : r.vw;
+    if (vws + n - r.vr > kRing) break;
+#ifndef ABLF_NODMA
+    const unsigned char* g = r.src + (size_t)r.qi * 1024 + lane16;
+    unsigned char* l = ring + ((vws & (kRing - 1)) << 10);
+    for (int k = wave; k < n; k += 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)k * 1024),
+                                       (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
+#endif
+    r.own_issued += own_share(n, wave);
+    r.qi += n;
+    r.vw = vws + n;
+    if (--r.ileft == 0) {
+      r.iseg = r.iseg + 1 == r.nseg ? 0 : r.iseg + 1;
+      segment<NT1, NT2, NT3, P>(r.iseg, r.ks0, r.nt0, r.ileft, r.isize);
+    }
+  }
+}
+// in front of a slab of n pieces: returns this lane's read address of the slab's first piece
+template <int NT1, int NT2, int NT3, int P>
+__device__ __forceinline__ const unsigned char* ring_boundary(Ring& r, unsigned char* ring, int n, int wave, int lane16) {
+  const int pr = r.vr & (kRing - 1);
+  if (pr + n > kRing) r.vr += kRing - pr;
+  r.own_needed += own_share(n, wave);
+#ifndef ABLF_NOWAIT
+  wait_vmcnt_le(r.own_issued - r.own_needed);
+#endif
+#ifndef ABLF_NOBAR
+  asm volatile("s_barrier" ::: "memory");
+#else
+  asm volatile("" ::: "memory");
+#endif
+  ring_issue<NT1, NT2, NT3, P>(r, ring, wave, lane16);
+  return ring + ((r.vr & (kRing - 1)) << 10) + lane16;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int P>
+struct FragV { u32x4 p[P]; };
+// block b (P pieces) of the slab at `base`
+template <int P>
+__device__ __forceinline__ void read_frag(const unsigned char* base, int b, FragV<P>& f) {
+#pragma unroll
+  for (int p = 0; p < P; p++) f.p[p] = *reinterpret_cast<const u32x4*>(base + (b * P + p) * 1024);
+}
+template <int P>
+__device__ __forceinline__ void mma_frag(const FragV<P>& a, const FragV<P>& b, f32x16& acc) {
+#ifdef ABLF_NOMMA   // timing experiment only: operands kept alive, no matrix instruction
+#pragma unroll
+  for (int i = 0; i < P; i++) asm volatile("" ::"v"(a.p[i]), "v"(b.p[i]));
+  return;
+#endif
+  if constexpr (P == 3) {   // smallest terms first
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, a.p[0]), am = __builtin_bit_cast(bf16x8, a.p[1]), al = __builtin_bit_cast(bf16x8, a.p[2]);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, b.p[0]), bm = __builtin_bit_cast(bf16x8, b.p[1]), bl = __builtin_bit_cast(bf16x8, b.p[2]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  } else {
+    const f16x8 ah = __builtin_bit_cast(f16x8, a.p[0]), al = __builtin_bit_cast(f16x8, a.p[1]);
+    const f16x8 bh = __builtin_bit_cast(f16x8, b.p[0]), bl = __builtin_bit_cast(f16x8, b.p[1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+  }
+}
+
+// "these values exist here": the compiler may not sink the (register-only) arithmetic that makes them past this point.  It
+// does otherwise -- a fragment converted during k-step ks for k-step ks + 1 ends up converted at the top of k-step ks + 1,
+// in front of the MFMAs that wait for it, with the matrix pipe idle meanwhile.
+template <int P>
+__device__ __forceinline__ void pin(FragV<P>& f) {
+#pragma unroll
+  for (int p = 0; p < P; p++) asm volatile("" : "+v"(f.p[p]));
+}
+__device__ __forceinline__ void pin(f32x16& t) { asm volatile("" : "+v"(t)); }
+
+// two fp32 values (elements 2 i, 2 i + 1 of a k-step's fragment) -> word i of every plane
+template <int P>
+__device__ __forceinline__ void split_pair(float x0, float x1, float a_scale, int i, FragV<P>& f) {
+  if constexpr (P == 3) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(x0, h0, m0, l0);
+    split3(x1, h1, m1, l1);
+    f.p[0][i] = pack_hi16(h0, h1); f.p[1][i] = pack_hi16(m0, m1); f.p[2][i] = pack_hi16(l0, l1);
+  } else {
+    unsigned h, l;
+    split2(x0 * a_scale, x1 * a_scale, h, l);
+    f.p[0][i] = h; f.p[1][i] = l;
+  }
+}
+// pair i of k-step ks of X (k-step ks = registers 8 (ks & 1) .. + 7 of tile ks >> 1)
+template <int P, int NTX>
+__device__ __forceinline__ void split_pair_of(const f32x16 (&X)[NTX], int ks, int i, float a_scale, FragV<P>& f) {
+  split_pair<P>(X[ks >> 1][8 * (ks & 1) + 2 * i], X[ks >> 1][8 * (ks & 1) + 2 * i + 1], a_scale, i, f);
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&X)[NT]) {
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) X[nt][r] = 0.f;
+}
+
+#define RING_T NT1, NT2, NT3, P   // the shape parameters the ring's slab sequence depends on
+
+// Order of a block's instructions, pinned (LLVM sched_group_barrier): the P fragment reads of the NEXT block first, then the
+// block's MFMAs one at a time with up to four vector instructions behind each.  A wave issues in order and is alone on its
+// SIMD: left to itself the compiler (short of registers) reads every fragment right in front of the MFMA that needs it
+// -- an LDS round trip per two MFMAs -- and bunches the conversions and epilogues between the MFMA groups, where the matrix
+// pipe waits for them.
+#ifndef ANI_FUSED_VALU_PER_MFMA
+#define ANI_FUSED_VALU_PER_MFMA 4
+#endif
+template <int P>
+__device__ __forceinline__ void sched_first_read() {   // the slab's first block has nobody to be requested behind
+#ifndef ABLF_NOSCHED
+  __builtin_amdgcn_sched_group_barrier(0x100, P, 0);
+#endif
+}
+template <int P, bool READ>
+__device__ __forceinline__ void sched_block() {
+#ifndef ABLF_NOSCHED
+  if constexpr (READ) __builtin_amdgcn_sched_group_barrier(0x100, P, 0);
+#pragma unroll
+  for (int i = 0; i < (P == 3 ? 6 : 3); i++) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, ANI_FUSED_VALU_PER_MFMA, 0);
+  }
+#endif
+}
+
+// acc[NT] += W (stream) * X  with X in registers: KS k-steps.  The fragments of block i + 1 are requested before the MFMAs
+// of block i (two register sets, statically alternated); the 16-bit terms of k-step ks + 1 are made a pair per block during
+// k-step ks.
+template <int NT1, int NT2, int NT3, int KS, int NT, int NTX, int P>
+__device__ __forceinline__ void product_reg(Ring& r, unsigned char* ring, const f32x16 (&X)[NTX], f32x16 (&acc)[NT], float a_scale,
+                                            int wave, int lane16) {
+  static_assert(KS <= 2 * NTX, "k-steps beyond the source tiles");
+  FragV<P> bq[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) split_pair_of<P>(X, 0, i, a_scale, bq[0]);
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) {
+    const unsigned char* base = ring_boundary<RING_T>(r, ring, NT * P, wave, lane16);
+    FragV<P> fa[2];
+    read_frag<P>(base, 0, fa[0]);
+    sched_first_read<P>();
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      if (nt + 1 < NT) read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if ((i < NT ? i : NT - 1) == nt) split_pair_of<P>(X, ks + 1, i, a_scale, bq[(ks + 1) & 1]);
+      }
+      mma_frag<P>(fa[nt & 1], bq[ks & 1], acc[nt]);
+      if (nt + 1 < NT) sched_block<P, true>(); else sched_block<P, false>();
+    }
+    if (ks + 1 < KS) pin<P>(bq[(ks + 1) & 1]);
+    r.vr += NT * P;
+  }
+}
+
+// The hidden backward products, in place:  Y[nt] <- (sum_ks W[nt][ks] X[ks]) * inv * celu'(z[nt]),  Y holding the stored
+// activation (through which celu' is known) on entry and the gradient on exit -- no second set of tiles.  The source X is
+// split into its 16-bit terms once (it is dead afterwards: 12 registers per k-step instead of 8), during the first output
+// tile's pass; then one output tile at a time runs through all k-steps on one accumulator (two, alternated: the masking of
+// tile nt - 1 sits among the first MFMAs of tile nt).  A slab is the KS blocks of an output tile.
+template <int NT1, int NT2, int NT3, int KS, int NT, int NTX, int P>
+__device__ __forceinline__ void product_inplace(Ring& r, unsigned char* ring, const f32x16 (&X)[NTX], f32x16 (&Y)[NT], float a_scale,
+                                                float inv, float inv_alpha, int wave, int lane16) {
+  static_assert(KS <= 2 * NTX, "k-steps beyond the source tiles");
+  FragV<P> bf[KS];
+#pragma unroll
+  for (int i = 0; i < 4; i++) split_pair_of<P>(X, 0, i, a_scale, bf[0]);
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    const unsigned char* base = ring_boundary<RING_T>(r, ring, KS * P, wave, lane16);
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[nt & 1][i] = 0.f;
+    FragV<P> fa[2];
+    read_frag<P>(base, 0, fa[0]);
+    sched_first_read<P>();
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      if (ks + 1 < KS) read_frag<P>(base, ks + 1, fa[(ks + 1) & 1]);
+      if (nt == 0 && ks + 1 < KS) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) split_pair_of<P>(X, ks + 1, i, a_scale, bf[ks + 1]);
+      }
+      mma_frag<P>(fa[ks & 1], bf[ks], acc[nt & 1]);
+      if (ks == 1 && nt > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) Y[nt - 1][i] = acc[(nt - 1) & 1][i] * inv * dcelu_from_h(Y[nt - 1][i], inv_alpha);
+      }
+      if (ks + 1 < KS) sched_block<P, true>(); else sched_block<P, false>();
+      if (nt == 0 && ks + 1 < KS) pin<P>(bf[ks + 1]);
+      if (ks == 3 && nt > 0) pin(Y[nt - 1]);
+    }
+    r.vr += KS * P;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) Y[NT - 1][i] = acc[(NT - 1) & 1][i] * inv * dcelu_from_h(Y[NT - 1][i], inv_alpha);
+}
+
+// constants of a member in LDS (floats): b0[32 NT1] b1[32 NT2] b2[32 NT3] w3[32 NT3] then {b3, inv[6]}
+template <int NT1, int NT2, int NT3>
+struct ConstLayout {
+  static constexpr int b0 = 0, b1 = 32 * NT1, b2 = b1 + 32 * NT2, w3 = b2 + 32 * NT3, tail = w3 + 32 * NT3, count = tail + 8;
+};
+
+template <int NT>
+__device__ __forceinline__ void epilogue_celu(f32x16 (&X)[NT], const float* b, int h, float inv, float alpha, float inv_alpha) {
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 bv = *reinterpret_cast<const float4*>(b + 32 * nt + 8 * q + 4 * h);
+      X[nt][4 * q + 0] = celu_f(fmaf(X[nt][4 * q + 0], inv, bv.x), alpha, inv_alpha);
+      X[nt][4 * q + 1] = celu_f(fmaf(X[nt][4 * q + 1], inv, bv.y), alpha, inv_alpha);
+      X[nt][4 * q + 2] = celu_f(fmaf(X[nt][4 * q + 2], inv, bv.z), alpha, inv_alpha);
+      X[nt][4 * q + 3] = celu_f(fmaf(X[nt][4 * q + 3], inv, bv.w), alpha, inv_alpha);
+    }
+}
+
+struct TileCtx {
+  float alpha, inv_alpha, scale, a_fwd, a_bwd;
+  int M;
+};
+
+// One 128-row tile of a species bucket, all members.  Shape (NT1, NT2, NT3): 32-feature tiles of the three hidden layers
+// (widths padded with zero weights).
+template <int NT1, int NT2, int NT3, int P>
+__device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& pr, int tile, int wave, int lane, unsigned char* ring,
+                                           float* cst) {
+  using CL = ConstLayout<NT1, NT2, NT3>;
+  static_assert(CL::count * 4 <= kConstBytes, "constants do not fit their LDS block");
+  static_assert(2 * NT2 * P <= kRing / 2 && NT1 * P <= kRing / 2, "a slab must fit the ring at least twice");
+  const int c = lane & 31, h = lane >> 5, lane16 = lane * 16;
+  const int row = tile * 128 + 32 * wave + c;
+  const float valid = pr.centre_of_row[row] >= 0 ? cx.scale : 0.f;
+  const float* __restrict__ arow = pr.aev + (size_t)row * pr.aev_stride + 4 * h;
+  float* __restrict__ grow = pr.gaev + (size_t)row * pr.aev_stride + 4 * h;
+  Ring r;
+  r.src = pr.stream; r.total = pr.pieces_per_member * cx.M; r.qi = 0;
+  r.ks0 = pr.ks0; r.nt0 = pr.nt0;
+  r.iseg = 0; r.nseg = 5 + (pr.nt0 + kChunk - 1) / kChunk;
+  segment<NT1, NT2, NT3, P>(0, r.ks0, r.nt0, r.ileft, r.isize);
+  r.vw = 0; r.vr = 0; r.own_issued = 0; r.own_needed = 0;
+  FUSED_STAMP_INIT();
+  ring_issue<RING_T>(r, ring, wave, lane16);
+
+  for (int m = 0; m < cx.M; m++) {
+    // the member's constants: one piece per wave, then everything issued so far is waited for (the ring's first slabs among
+    // it: they are needed next anyway)
+    {
+      const int nconst = (CL::count * 4 + 1023) >> 10;
+      if (wave < nconst) {
+        const unsigned char* g = reinterpret_cast<const unsigned char*>(pr.consts + (size_t)m * pr.consts_per_member) + wave * 1024 + lane16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(cst) + wave * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    const float inv_f1 = cst[CL::tail + 1], inv_f2 = cst[CL::tail + 2], inv_f3 = cst[CL::tail + 3];
+    const float inv_b3 = cst[CL::tail + 4], inv_b2 = cst[CL::tail + 5], inv_b1 = cst[CL::tail + 6];
+    const float b3 = cst[CL::tail];
+    FUSED_STAMP(0);
+
+    // ---- F1: h1 = celu(W0 aev + b0); the B operand streams from the AEV rows (two k-steps ahead) ----
+    f32x16 X1[NT1];
+    zero_tiles(X1);
+    {
+      const int ks0 = pr.ks0;
+      float4 na = make_float4(0, 0, 0, 0), nb = na, ma = na, mb = na;
+      if (0 < ks0) { na = *reinterpret_cast<const float4*>(arow); nb = *reinterpret_cast<const float4*>(arow + 8); }
+      if (1 < ks0) { ma = *reinterpret_cast<const float4*>(arow + 16); mb = *reinterpret_cast<const float4*>(arow + 24); }
+      FragV<P> bcur, bnxt;
+      split_pair<P>(na.x, na.y, cx.a_fwd, 0, bcur); split_pair<P>(na.z, na.w, cx.a_fwd, 1, bcur);
+      split_pair<P>(nb.x, nb.y, cx.a_fwd, 2, bcur); split_pair<P>(nb.z, nb.w, cx.a_fwd, 3, bcur);
+      bnxt = bcur;
+      for (int ks = 0; ks < ks0; ks++) {
+        const unsigned char* base = ring_boundary<RING_T>(r, ring, NT1 * P, wave, lane16);
+        // the values of k-step ks + 1 are in (ma, mb); k-step ks + 2 is requested now
+        const float4 va = ma, vb = mb;
+        if (ks + 2 < ks0) {
+          ma = *reinterpret_cast<const float4*>(arow + 16 * (ks + 2));
+          mb = *reinterpret_cast<const float4*>(arow + 16 * (ks + 2) + 8);
+        }
+        FragV<P> fa[2];
+        read_frag<P>(base, 0, fa[0]);
+    sched_first_read<P>();
+#pragma unroll
+        for (int nt = 0; nt < NT1; nt++) {
+          if (nt + 1 < NT1) read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
+          if (nt == 0) split_pair<P>(va.x, va.y, cx.a_fwd, 0, bnxt);
+          if (nt == 1) split_pair<P>(va.z, va.w, cx.a_fwd, 1, bnxt);
+          if (nt == 2) split_pair<P>(vb.x, vb.y, cx.a_fwd, 2, bnxt);
+          if (nt == 3) split_pair<P>(vb.z, vb.w, cx.a_fwd, 3, bnxt);
+          mma_frag<P>(fa[nt & 1], bcur, X1[nt]);
+          if (nt + 1 < NT1) sched_block<P, true>(); else sched_block<P, false>();
+        }
+        pin<P>(bnxt);
+        bcur = bnxt;
+        r.vr += NT1 * P;
+      }
+    }
+    FUSED_STAMP(1);
+    epilogue_celu(X1, cst + CL::b0, h, inv_f1, cx.alpha, cx.inv_alpha);
+    FUSED_STAMP(2);
+
+    // ---- F2, F3 ----
+    f32x16 X2[NT2];
+    zero_tiles(X2);
+    product_reg<NT1, NT2, NT3, 2 * NT1, NT2, NT1, P>(r, ring, X1, X2, cx.a_fwd, wave, lane16);
+    FUSED_STAMP(3);
+    epilogue_celu(X2, cst + CL::b1, h, inv_f2, cx.alpha, cx.inv_alpha);
+    FUSED_STAMP(4);
+
+    f32x16 X3[NT3];
+    zero_tiles(X3);
+    product_reg<NT1, NT2, NT3, 2 * NT2, NT3, NT2, P>(r, ring, X2, X3, cx.a_fwd, wave, lane16);
+    FUSED_STAMP(5);
+    // last hidden layer fused with the 1-wide output layer and the backward seed dE/dz3 = (1/M) w3 celu'(z3)
+    {
+      float es = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT3; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 bv = *reinterpret_cast<const float4*>(cst + CL::b2 + 32 * nt + 8 * q + 4 * h);
+          const float4 wv = *reinterpret_cast<const float4*>(cst + CL::w3 + 32 * nt + 8 * q + 4 * h);
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float hv = celu_f(fmaf(X3[nt][4 * q + i], inv_f3, bb[i]), cx.alpha, cx.inv_alpha);
+            es = fmaf(hv, ww[i], es);
+            X3[nt][4 * q + i] = valid * ww[i] * dcelu_from_h(hv, cx.inv_alpha);
+          }
+        }
+      es += __shfl_xor(es, 32);
+      if (h == 0) pr.e_rows[(size_t)m * pr.sE + row] = valid * (es + b3);
+    }
+
+    FUSED_STAMP(6);
+    // ---- B3: g2 = (W2^T g3) celu'(z2), written over h2 ; B2: g1 = (W1^T g2) celu'(z1), written over h1 ----
+    product_inplace<NT1, NT2, NT3, 2 * NT3, NT2, NT3, P>(r, ring, X3, X2, cx.a_bwd, inv_b3, cx.inv_alpha, wave, lane16);
+    FUSED_STAMP(7);
+    product_inplace<NT1, NT2, NT3, 2 * NT2, NT1, NT2, P>(r, ring, X2, X1, cx.a_bwd, inv_b2, cx.inv_alpha, wave, lane16);
+    FUSED_STAMP(8);
+    f32x16 (&G1)[NT1] = X1;
+
+    // ---- B1: dE/dAEV = W0^T g1, kChunk 32-column tiles at a time; members after the first add to what is there ----
+    for (int c0 = 0; c0 < pr.nt0; c0 += kChunk) {
+      const int ntc = min(kChunk, pr.nt0 - c0);
+      f32x16 acc[kChunk];
+      zero_tiles(acc);
+      FragV<P> bq[2];
+#pragma unroll
+      for (int i = 0; i < 4; i++) split_pair_of<P>(G1, 0, i, cx.a_bwd, bq[0]);
+#pragma unroll
+      for (int ks = 0; ks < 2 * NT1; ks++) {
+        const unsigned char* base = ring_boundary<RING_T>(r, ring, ntc * P, wave, lane16);
+        FragV<P> fa[2];
+        read_frag<P>(base, 0, fa[0]);
+        sched_first_read<P>();
+        if (ntc == kChunk) {   // the usual case, free of branches: one scheduling region per k-step
+#pragma unroll
+          for (int t = 0; t < kChunk; t++) {
+            if (t + 1 < kChunk) read_frag<P>(base, t + 1, fa[(t + 1) & 1]);
+            if (ks + 1 < 2 * NT1) split_pair_of<P>(G1, ks + 1, t, cx.a_bwd, bq[(ks + 1) & 1]);
+            mma_frag<P>(fa[t & 1], bq[ks & 1], acc[t]);
+            if (t + 1 < kChunk) sched_block<P, true>(); else sched_block<P, false>();
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < kChunk; t++) {
+            if (t < ntc) {
+              if (t + 1 < ntc) read_frag<P>(base, t + 1, fa[(t + 1) & 1]);
+              mma_frag<P>(fa[t & 1], bq[ks & 1], acc[t]);
+            }
+          }
+          if (ks + 1 < 2 * NT1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) split_pair_of<P>(G1, ks + 1, i, cx.a_bwd, bq[(ks + 1) & 1]);
+          }
+        }
+        if (ks + 1 < 2 * NT1) pin<P>(bq[(ks + 1) & 1]);
+        r.vr += ntc * P;
+      }
+#pragma unroll
+      for (int t = 0; t < kChunk; t++) {
+        if (t < ntc) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int f0 = 32 * (c0 + t) + 8 * q;   // + 4 h is in grow
+            if (f0 + 4 * h < pr.acols) {
+              float4 o = make_float4(acc[t][4 * q] * inv_b1, acc[t][4 * q + 1] * inv_b1, acc[t][4 * q + 2] * inv_b1, acc[t][4 * q + 3] * inv_b1);
+              float4* dst = reinterpret_cast<float4*>(grow + f0);
+              if (m > 0) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+              *dst = o;
+            }
+          }
+        }
+      }
+    }
+    FUSED_STAMP(9);
+  }
+}
+#undef RING_T
+
+template <int P>
+__global__ __launch_bounds__(256, 1) void mlp_fused(FusedArgs G) {
+  extern __shared__ uint4 smem4[];
+  unsigned char* ring = reinterpret_cast<unsigned char*>(smem4);
+  float* cst = reinterpret_cast<float*>(ring + kRing * 1024);
+  __shared__ int s_tile;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  TileCtx cx;
+  cx.alpha = G.alpha; cx.inv_alpha = G.inv_alpha; cx.scale = G.scale; cx.M = G.M;
+  cx.a_fwd = P == 2 ? 16.f : 1.f; cx.a_bwd = P == 2 ? 4096.f : 1.f;
+  const int total = G.tile_start[G.nprob];
+  for (;;) {
+    __syncthreads();   // every wave is done with the tile before (ring, constants, s_tile)
+    if (threadIdx.x == 0) s_tile = atomicAdd(G.counter, 1);
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(s_tile);
+    if (t >= total) break;
+    int pi = 0;
+    while (pi + 1 < G.nprob && t >= G.tile_start[pi + 1]) pi++;
+    const FusedProb& pr = G.p[pi];
+    const int tile = t - G.tile_start[pi];
+    switch (pr.shape) {
+      case 0: fused_tile<8, 6, 5, P>(cx, pr, tile, wave, lane, ring, cst); break;
+      case 1: fused_tile<6, 5, 4, P>(cx, pr, tile, wave, lane, ring, cst); break;
+      default: fused_tile<5, 4, 3, P>(cx, pr, tile, wave, lane, ring, cst); break;
+    }
+  }
+}
+
+const int kShapes[3][3] = {{8, 6, 5}, {6, 5, 4}, {5, 4, 3}};
+
+int fused_shape_for(int d1, int d2, int d3) {
+  for (int s = 2; s >= 0; s--)
+    if (d1 <= 32 * kShapes[s][0] && d2 <= 32 * kShapes[s][1] && d3 <= 32 * kShapes[s][2]) return s;
+  return -1;
+}
+void fused_shape_tiles(int shape, int nt[3]) { for (int k = 0; k < 3; k++) nt[k] = kShapes[shape][k]; }
+int fused_consts_floats(int shape) {
+  const int* s = kShapes[shape];
+  const int n = 32 * (s[0] + s[1] + 2 * s[2]) + 8;
+  return (n + 255) / 256 * 256;   // whole 1 KB pieces
+}
+long long fused_pieces_per_member(int shape, int acols, int P) {
+  const int* s = kShapes[shape];
+  const long long ks0 = acols / 16, nt0 = (acols + 31) / 32;
+  return P * (ks0 * s[0] + 2LL * s[0] * s[1] + 2LL * s[1] * s[2] + 2LL * s[2] * s[1] + 2LL * s[1] * s[0] + 2LL * s[0] * nt0);
+}
+
+int fused_read_stamps(unsigned long long* out16, int reset) {
+#ifdef ABLF_STAMPS
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 1;
+#else
+  (void)out16; (void)reset;
+  return 0;
+#endif
+}
+
+void launch_build_stream(const float* src, int ld, int rows_valid, int k_valid, int NT, int KS, int chunk, int P, float scale,
+                         unsigned short* dst, hipStream_t st) {
+  const long long total = (long long)NT * KS * 512;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(build_stream_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, ld, rows_valid, k_valid, NT, KS,
+                     chunk, P, scale, dst);
+}
+
+hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st) {
+  static int ncu = [] {
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) note_launch_error(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    return v > 0 ? v : 256;
+  }();
+  const int total = G.tile_start[G.nprob];
+  if (total <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(G.counter, 0, sizeof(int), st);
+  if (e != hipSuccess) return e;
+  const int pi = arith == MLP_F16X2 ? 1 : 0;
+  const void* fn = pi ? (const void*)mlp_fused<2> : (const void*)mlp_fused<3>;
+  {
+    // raising the dynamic-LDS limit is per kernel and device: once each
+    static std::set<std::pair<int, const void*>> raised;
+    static std::mutex mtx;
+    int dev = 0;
+    e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mtx);
+    if (!raised.count(std::make_pair(dev, fn))) {
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds);
+      if (e != hipSuccess) return e;
+      raised.insert(std::make_pair(dev, fn));
+    }
+  }
+  const int grid = total < ncu ? total : ncu;
+  if (pi) hipLaunchKernelGGL(mlp_fused<2>, dim3(grid), dim3(256), kFusedLds, st, G);
+  else hipLaunchKernelGGL(mlp_fused<3>, dim3(grid), dim3(256), kFusedLds, st, G);
+  return hipGetLastError();
+}
+
+}  // namespace ani
