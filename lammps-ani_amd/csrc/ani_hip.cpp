@@ -597,6 +597,7 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
   FusedArgs G{};
   G.M = m.M; G.alpha = (float)m.alpha; G.inv_alpha = (float)(1.0 / m.alpha); G.scale = 1.f / (float)m.M;
   G.counter = h->fused_counter.p;
+  G.err_flag = h->err_flag.p;
   const int acols = h->ap_run.aev_len, ka = h->ap_run.aev_stride;
   int np = 0, total = 0;
   for (int shape = 0; shape < 3; shape++)        // costliest species first

@@ -110,6 +110,7 @@ struct FusedArgs {
   int nprob, M;
   float alpha, inv_alpha, scale;      // CELU; scale = 1 / M
   int* counter;                       // device word the workgroups draw tiles from (zeroed by the launcher)
+  int* err_flag;                      // device error word: bit 4 = the weight ring's schedule broke (cannot happen: tests/ring_sim.cpp)
 };
 int fused_shape_for(int d1, int d2, int d3);          // -1: no compiled shape holds these widths
 void fused_shape_tiles(int shape, int nt[3]);         // 32-feature tiles of the three hidden layers

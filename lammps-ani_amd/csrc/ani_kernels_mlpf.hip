@@ -42,19 +42,17 @@
 #include <utility>
 #include <vector>
 
+#include "ani_fused_ring.h"
 #include "ani_kernels.h"
 #include "ani_mlp_common.h"
 
 namespace ani {
 
-#ifndef ANI_FUSED_RING
-#define ANI_FUSED_RING 128
-#endif
-constexpr int kRing = ANI_FUSED_RING;      // pieces (KB) in the LDS ring; power of two
 // timing-only ablation switches (wrong results): ABLF_NOWAIT no wait for the pieces of a slab, ABLF_NOBAR no barrier in
 // front of a slab, ABLF_NOMMA no MFMAs, ABLF_NODMA no weight loads
 constexpr int kConstBytes = 4096;          // LDS copy of a member's biases / output layer
 constexpr int kFusedLds = kRing * 1024 + kConstBytes;
+static_assert(kFusedLds + 64 <= 160 * 1024, "ring + constants exceed the LDS of a CU");
 
 // diagnostic build (-DABLF_STAMPS): wave 0 of every workgroup adds the shader-clock cycles it spent in each phase of a tile
 // to g_fused_stamps (read by ani_debug_fused_stamps); no stamp executes in the shipped kernel
@@ -124,23 +122,7 @@ __global__ void build_stream_kernel(const float* __restrict__ src, int ld, int r
   }
 }
 
-// ---- the ring -----------------------------------------------------------------------------------------------------------
-// A slab (the pieces of one k-step of a forward product, of one output tile of a hidden backward product) never wraps: a
-// slab that would cross the ring's end starts at its beginning instead, issuer and consumer applying the same rule to
-// the same sequence of slab sizes.  Inside a slab every fragment is then at a compile-time offset from one base address
-// (ds_read_b128 ... offset:imm): no address arithmetic per piece.
-struct Ring {
-  const unsigned char* src;   // the tile's weight stream (global), members back to back
-  int total;                  // pieces in it
-  int qi;                     // next piece of the stream to issue
-  int iseg, nseg;             // issuer: segment (see segment()) of the next slab to issue; segments per member
-  int ileft, isize;           // issuer: slabs left in that segment, pieces per slab of it
-  int vw;                     // issuer: virtual write position (pieces, skipped space included; position = vw mod kRing)
-  int vr;                     // consumer: virtual position of the slab being consumed
-  int own_issued, own_needed; // pieces this wave has issued / that the slabs consumed so far needed from this wave
-  int ks0, nt0;               // AEV k-steps / dE/dAEV tiles of the problem (the slab sequence depends on them)
-};
-
+// ---- the ring (bookkeeping: ani_fused_ring.h) ---------------------------------------------------------------------
 __device__ __forceinline__ void wait_vmcnt_le(int c) {
   // "all but the c youngest vector-memory operations of this wave are done".  Rounded down to one of four immediates
   // (waiting for a few more pieces, issued at least a slab ago, costs nothing; a long chain of cases did); younger loads /
@@ -150,64 +132,69 @@ __device__ __forceinline__ void wait_vmcnt_le(int c) {
   else if (c >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-// pieces k = wave, wave + 4, ... < n of a slab: this wave's share
-__device__ __forceinline__ int own_share(int n, int wave) { return (n - wave + 3) >> 2; }
-
-// A member's slabs come in SEGMENTS of equal slabs:  F1 ks0 x [NT1]  F2 2NT1 x [NT2]  F3 2NT2 x [NT3]  B3 NT2 x [2NT3]
-// B2 NT1 x [2NT2]  then per chunk of kChunk dE/dAEV tiles 2NT1 x [tiles of the chunk]   (sizes times P).  The issuer looks a
-// segment up when it enters it, not per slab.
-constexpr int kChunk = 4;   // dE/dAEV tiles walked together through all k-steps (accumulators: 16 registers each)
-template <int NT1, int NT2, int NT3, int P>
-__device__ __forceinline__ void segment(int seg, int ks0, int nt0, int& count, int& size) {
-  if (seg == 0) { count = ks0; size = NT1 * P; }
-  else if (seg == 1) { count = 2 * NT1; size = NT2 * P; }
-  else if (seg == 2) { count = 2 * NT2; size = NT3 * P; }
-  else if (seg == 3) { count = NT2; size = 2 * NT3 * P; }
-  else if (seg == 4) { count = NT1; size = 2 * NT2 * P; }
-  else { count = 2 * NT1; size = min(kChunk, nt0 - kChunk * (seg - 5)) * P; }
-}
-
 // refill: every whole slab that fits behind the consumer
 template <int NT1, int NT2, int NT3, int P>
 __device__ __forceinline__ void ring_issue(Ring& r, unsigned char* ring, int wave, int lane16) {
-  while (r.qi < r.total) {
-    const int n = r.isize;
-    const int pw = r.vw & (kRing - 1);
-    const int vws = pw + n > kRing ? r.vw + (kRing - pw) : r.vw;
-    if (vws + n - r.vr > kRing) break;
+  int q0, pos, n;
+  while (ring_take<NT1, NT2, NT3, P>(r, wave, q0, pos, n)) {
 #ifndef ABLF_NODMA
-    const unsigned char* g = r.src + (size_t)r.qi * 1024 + lane16;
-    unsigned char* l = ring + ((vws & (kRing - 1)) << 10);
+    const unsigned char* g = r.src + (size_t)q0 * 1024 + lane16;
+    unsigned char* l = ring + (pos << 10);
     for (int k = wave; k < n; k += 4)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)k * 1024),
                                        (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
 #endif
-    r.own_issued += own_share(n, wave);
-    r.qi += n;
-    r.vw = vws + n;
-    if (--r.ileft == 0) {
-      r.iseg = r.iseg + 1 == r.nseg ? 0 : r.iseg + 1;
-      segment<NT1, NT2, NT3, P>(r.iseg, r.ks0, r.nt0, r.ileft, r.isize);
-    }
   }
 }
-// in front of a slab of n pieces: returns this lane's read address of the slab's first piece
-template <int NT1, int NT2, int NT3, int P>
-__device__ __forceinline__ const unsigned char* ring_boundary(Ring& r, unsigned char* ring, int n, int wave, int lane16) {
-  const int pr = r.vr & (kRing - 1);
-  if (pr + n > kRing) r.vr += kRing - pr;
-  r.own_needed += own_share(n, wave);
+// In front of a slab of n pieces: returns this lane's read address of the slab's first piece.  EARLY: see ani_fused_ring.h --
+// the call sits in front of the LAST block of the slab before, so that the new slab's first fragments are requested beside
+// that block's MFMAs instead of after them (an LDS round trip with an idle matrix pipe per slab otherwise).
+template <int NT1, int NT2, int NT3, int P, bool EARLY>
+__device__ __forceinline__ const unsigned char* ring_boundary(Ring& r, unsigned char* ring, int n, int wave, int lane16, int* err_flag) {
+  const int vs = ring_place(r, n);
+  if (!EARLY && !ring_issued(r, n)) {
+    // rare (ani_fused_ring.h): the slab is not on its way yet.  Every older slab is finished once all waves are here: free
+    // the ring, request it, then wait for it like for any other
+    asm volatile("s_barrier" ::: "memory");
+    ring_before_refill<false>(r, vs);
+    ring_issue<NT1, NT2, NT3, P>(r, ring, wave, lane16);
+  }
+  int allowed = ring_grant(r, n, wave);
+  if (allowed < 0 || !(r.qg <= r.qi)) {   // cannot happen (tests/ring_sim.cpp); never silently: the step's energy becomes NaN
+    if (lane16 == 0) atomicOr(err_flag, 4);
+    allowed = 0;
+  }
 #ifndef ABLF_NOWAIT
-  wait_vmcnt_le(r.own_issued - r.own_needed);
+  wait_vmcnt_le(allowed);
 #endif
 #ifndef ABLF_NOBAR
   asm volatile("s_barrier" ::: "memory");
 #else
   asm volatile("" ::: "memory");
 #endif
+  ring_before_refill<EARLY>(r, vs);
   ring_issue<NT1, NT2, NT3, P>(r, ring, wave, lane16);
-  return ring + ((r.vr & (kRing - 1)) << 10) + lane16;
+  ring_after_refill(r, vs, n);
+  return ring + (ring_pos(vs) << 10) + lane16;
 }
+// The boundary of a slab that follows another of the same product: early -- in front of the last block of the slab being
+// read, so that the new slab's first fragments are requested beside that block's MFMAs -- if the slab is already on its way,
+// else late, behind that block.  FUSED_NEXT_SLAB_EARLY goes in front of the last block's MFMAs, FUSED_NEXT_SLAB_LATE behind.
+#define FUSED_NEXT_SLAB_EARLY(n_, frag_)                                                            \
+  bool late_ = false;                                                                               \
+  if (ring_can_go_early(r, (n_))) {                                                                 \
+    base = ring_boundary<RING_T, true>(r, ring, (n_), wave, lane16, err);                           \
+    read_frag<P>(base, 0, frag_);                                                                   \
+    sched_first_read<P>();                                                                          \
+  } else {                                                                                          \
+    late_ = true;                                                                                   \
+  }
+#define FUSED_NEXT_SLAB_LATE(n_, frag_)                                                             \
+  if (late_) {                                                                                      \
+    base = ring_boundary<RING_T, false>(r, ring, (n_), wave, lane16, err);                          \
+    read_frag<P>(base, 0, frag_);                                                                   \
+    sched_first_read<P>();                                                                          \
+  }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int P>
@@ -215,6 +202,11 @@ struct FragV { u32x4 p[P]; };
 // block b (P pieces) of the slab at `base`
 template <int P>
 __device__ __forceinline__ void read_frag(const unsigned char* base, int b, FragV<P>& f) {
+#ifdef ABLF_NOLDS   // timing experiment only: no fragment reads (a value the compiler cannot fold)
+#pragma unroll
+  for (int p = 0; p < P; p++) { unsigned x = (unsigned)(size_t)base + b; asm volatile("" : "+v"(x)); f.p[p] = u32x4{x, x, x, x}; }
+  return;
+#endif
 #pragma unroll
   for (int p = 0; p < P; p++) f.p[p] = *reinterpret_cast<const u32x4*>(base + (b * P + p) * 1024);
 }
@@ -256,6 +248,11 @@ __device__ __forceinline__ void pin(f32x16& t) { asm volatile("" : "+v"(t)); }
 // two fp32 values (elements 2 i, 2 i + 1 of a k-step's fragment) -> word i of every plane
 template <int P>
 __device__ __forceinline__ void split_pair(float x0, float x1, float a_scale, int i, FragV<P>& f) {
+#ifdef ABLF_NOSPLIT   // timing experiment only: no conversion arithmetic (one move per plane)
+#pragma unroll
+  for (int p = 0; p < P; p++) f.p[p][i] = __float_as_uint(x0);
+  return;
+#endif
   if constexpr (P == 3) {
     unsigned h0, m0, l0, h1, m1, l1;
     split3(x0, h0, m0, l0);
@@ -309,35 +306,43 @@ __device__ __forceinline__ void sched_block() {
 #endif
 }
 
-// acc[NT] += W (stream) * X  with X in registers: KS k-steps.  The fragments of block i + 1 are requested before the MFMAs
-// of block i (two register sets, statically alternated); the 16-bit terms of k-step ks + 1 are made a pair per block during
-// k-step ks.
+// acc[NT] += W (stream) * X  with X in registers: KS k-steps, two per slab.  The fragments of block i + 1 are requested before
+// the MFMAs of block i (two register sets, statically alternated), across slabs too; the 16-bit terms of k-step ks + 1 are
+// made a pair per block during k-step ks.
 template <int NT1, int NT2, int NT3, int KS, int NT, int NTX, int P>
 __device__ __forceinline__ void product_reg(Ring& r, unsigned char* ring, const f32x16 (&X)[NTX], f32x16 (&acc)[NT], float a_scale,
-                                            int wave, int lane16) {
-  static_assert(KS <= 2 * NTX, "k-steps beyond the source tiles");
-  FragV<P> bq[2];
+                                            int wave, int lane16, int* err) {
+  static_assert(KS <= 2 * NTX && KS % 2 == 0, "k-steps beyond the source tiles");
+  constexpr int SB = 2 * NT;   // blocks per slab
+  FragV<P> bq[2], fa[2];
 #pragma unroll
   for (int i = 0; i < 4; i++) split_pair_of<P>(X, 0, i, a_scale, bq[0]);
+  const unsigned char* base = ring_boundary<RING_T, false>(r, ring, SB * P, wave, lane16, err);
+  read_frag<P>(base, 0, fa[0]);
+  sched_first_read<P>();
 #pragma unroll
-  for (int ks = 0; ks < KS; ks++) {
-    const unsigned char* base = ring_boundary<RING_T>(r, ring, NT * P, wave, lane16);
-    FragV<P> fa[2];
-    read_frag<P>(base, 0, fa[0]);
-    sched_first_read<P>();
+  for (int kp = 0; kp < KS / 2; kp++) {
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      if (nt + 1 < NT) read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
+    for (int j = 0; j < SB; j++) {
+      const int ks = 2 * kp + j / NT, nt = j % NT, idx = kp * SB + j;
+      const bool next_slab = j + 1 == SB && kp + 1 < KS / 2;
+      if (j + 1 < SB) read_frag<P>(base, j + 1, fa[(idx + 1) & 1]);
       if (ks + 1 < KS) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
           if ((i < NT ? i : NT - 1) == nt) split_pair_of<P>(X, ks + 1, i, a_scale, bq[(ks + 1) & 1]);
       }
-      mma_frag<P>(fa[nt & 1], bq[ks & 1], acc[nt]);
-      if (nt + 1 < NT) sched_block<P, true>(); else sched_block<P, false>();
+      if (next_slab) {
+        FUSED_NEXT_SLAB_EARLY(SB * P, fa[(idx + 1) & 1])
+        mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[nt]);
+        sched_block<P, false>();
+        FUSED_NEXT_SLAB_LATE(SB * P, fa[(idx + 1) & 1])
+      } else {
+        mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[nt]);
+        if (j + 1 < SB) sched_block<P, true>(); else sched_block<P, false>();
+      }
+      if (nt == NT - 1 && ks + 1 < KS) pin<P>(bq[(ks + 1) & 1]);
     }
-    if (ks + 1 < KS) pin<P>(bq[(ks + 1) & 1]);
-    r.vr += NT * P;
   }
 }
 
@@ -348,28 +353,35 @@ __device__ __forceinline__ void product_reg(Ring& r, unsigned char* ring, const 
 // tile nt - 1 sits among the first MFMAs of tile nt).  A slab is the KS blocks of an output tile.
 template <int NT1, int NT2, int NT3, int KS, int NT, int NTX, int P>
 __device__ __forceinline__ void product_inplace(Ring& r, unsigned char* ring, const f32x16 (&X)[NTX], f32x16 (&Y)[NT], float a_scale,
-                                                float inv, float inv_alpha, int wave, int lane16) {
+                                                float inv, float inv_alpha, int wave, int lane16, int* err) {
   static_assert(KS <= 2 * NTX, "k-steps beyond the source tiles");
-  FragV<P> bf[KS];
+  FragV<P> bf[KS], fa[2];
 #pragma unroll
   for (int i = 0; i < 4; i++) split_pair_of<P>(X, 0, i, a_scale, bf[0]);
   f32x16 acc[2];
+  const unsigned char* base = ring_boundary<RING_T, false>(r, ring, KS * P, wave, lane16, err);
+  read_frag<P>(base, 0, fa[0]);
+  sched_first_read<P>();
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) {
-    const unsigned char* base = ring_boundary<RING_T>(r, ring, KS * P, wave, lane16);
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[nt & 1][i] = 0.f;
-    FragV<P> fa[2];
-    read_frag<P>(base, 0, fa[0]);
-    sched_first_read<P>();
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-      if (ks + 1 < KS) read_frag<P>(base, ks + 1, fa[(ks + 1) & 1]);
+      const int idx = nt * KS + ks;
+      const bool next_slab = ks + 1 == KS && nt + 1 < NT;
+      if (ks + 1 < KS) read_frag<P>(base, ks + 1, fa[(idx + 1) & 1]);
       if (nt == 0 && ks + 1 < KS) {
 #pragma unroll
         for (int i = 0; i < 4; i++) split_pair_of<P>(X, ks + 1, i, a_scale, bf[ks + 1]);
       }
-      mma_frag<P>(fa[ks & 1], bf[ks], acc[nt & 1]);
+      if (next_slab) {
+        FUSED_NEXT_SLAB_EARLY(KS * P, fa[(idx + 1) & 1])
+        mma_frag<P>(fa[idx & 1], bf[ks], acc[nt & 1]);
+        FUSED_NEXT_SLAB_LATE(KS * P, fa[(idx + 1) & 1])
+      } else {
+        mma_frag<P>(fa[idx & 1], bf[ks], acc[nt & 1]);
+      }
       if (ks == 1 && nt > 0) {
 #pragma unroll
         for (int i = 0; i < 16; i++) Y[nt - 1][i] = acc[(nt - 1) & 1][i] * inv * dcelu_from_h(Y[nt - 1][i], inv_alpha);
@@ -378,7 +390,6 @@ __device__ __forceinline__ void product_inplace(Ring& r, unsigned char* ring, co
       if (nt == 0 && ks + 1 < KS) pin<P>(bf[ks + 1]);
       if (ks == 3 && nt > 0) pin(Y[nt - 1]);
     }
-    r.vr += KS * P;
   }
 #pragma unroll
   for (int i = 0; i < 16; i++) Y[NT - 1][i] = acc[(NT - 1) & 1][i] * inv * dcelu_from_h(Y[NT - 1][i], inv_alpha);
@@ -392,6 +403,9 @@ struct ConstLayout {
 
 template <int NT>
 __device__ __forceinline__ void epilogue_celu(f32x16 (&X)[NT], const float* b, int h, float inv, float alpha, float inv_alpha) {
+#ifdef ABLF_NOEPI   // timing experiment only
+  return;
+#endif
 #pragma unroll
   for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -407,6 +421,7 @@ __device__ __forceinline__ void epilogue_celu(f32x16 (&X)[NT], const float* b, i
 struct TileCtx {
   float alpha, inv_alpha, scale, a_fwd, a_bwd;
   int M;
+  int* err;   // device error word (bit 4: the ring schedule broke)
 };
 
 // One 128-row tile of a species bucket, all members.  Shape (NT1, NT2, NT3): 32-feature tiles of the three hidden layers
@@ -416,18 +431,16 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
                                            float* cst) {
   using CL = ConstLayout<NT1, NT2, NT3>;
   static_assert(CL::count * 4 <= kConstBytes, "constants do not fit their LDS block");
-  static_assert(2 * NT2 * P <= kRing / 2 && NT1 * P <= kRing / 2, "a slab must fit the ring at least twice");
+  static_assert(2 * 2 * NT2 * P <= kRing && 2 * F1Slab<NT1, P>::k * NT1 * P <= kRing && 2 * 2 * kChunk * P <= kRing,
+                "every slab must fit the ring at least twice");
   const int c = lane & 31, h = lane >> 5, lane16 = lane * 16;
+  int* const err = cx.err;
   const int row = tile * 128 + 32 * wave + c;
   const float valid = pr.centre_of_row[row] >= 0 ? cx.scale : 0.f;
   const float* __restrict__ arow = pr.aev + (size_t)row * pr.aev_stride + 4 * h;
   float* __restrict__ grow = pr.gaev + (size_t)row * pr.aev_stride + 4 * h;
   Ring r;
-  r.src = pr.stream; r.total = pr.pieces_per_member * cx.M; r.qi = 0;
-  r.ks0 = pr.ks0; r.nt0 = pr.nt0;
-  r.iseg = 0; r.nseg = 5 + (pr.nt0 + kChunk - 1) / kChunk;
-  segment<NT1, NT2, NT3, P>(0, r.ks0, r.nt0, r.ileft, r.isize);
-  r.vw = 0; r.vr = 0; r.own_issued = 0; r.own_needed = 0;
+  ring_reset<RING_T>(r, pr.stream, pr.pieces_per_member * cx.M, pr.ks0, pr.nt0);
   FUSED_STAMP_INIT();
   ring_issue<RING_T>(r, ring, wave, lane16);
 
@@ -448,42 +461,94 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
     const float b3 = cst[CL::tail];
     FUSED_STAMP(0);
 
-    // ---- F1: h1 = celu(W0 aev + b0); the B operand streams from the AEV rows (two k-steps ahead) ----
+    // ---- F1: h1 = celu(W0 aev + b0); the B operand streams from the AEV rows: K1 k-steps (one slab) per iteration, the
+    // rows' values requested a slab ahead ----
     f32x16 X1[NT1];
     zero_tiles(X1);
     {
-      const int ks0 = pr.ks0;
-      float4 na = make_float4(0, 0, 0, 0), nb = na, ma = na, mb = na;
-      if (0 < ks0) { na = *reinterpret_cast<const float4*>(arow); nb = *reinterpret_cast<const float4*>(arow + 8); }
-      if (1 < ks0) { ma = *reinterpret_cast<const float4*>(arow + 16); mb = *reinterpret_cast<const float4*>(arow + 24); }
-      FragV<P> bcur, bnxt;
-      split_pair<P>(na.x, na.y, cx.a_fwd, 0, bcur); split_pair<P>(na.z, na.w, cx.a_fwd, 1, bcur);
-      split_pair<P>(nb.x, nb.y, cx.a_fwd, 2, bcur); split_pair<P>(nb.z, nb.w, cx.a_fwd, 3, bcur);
-      bnxt = bcur;
-      for (int ks = 0; ks < ks0; ks++) {
-        const unsigned char* base = ring_boundary<RING_T>(r, ring, NT1 * P, wave, lane16);
-        // the values of k-step ks + 1 are in (ma, mb); k-step ks + 2 is requested now
-        const float4 va = ma, vb = mb;
-        if (ks + 2 < ks0) {
-          ma = *reinterpret_cast<const float4*>(arow + 16 * (ks + 2));
-          mb = *reinterpret_cast<const float4*>(arow + 16 * (ks + 2) + 8);
-        }
-        FragV<P> fa[2];
-        read_frag<P>(base, 0, fa[0]);
-    sched_first_read<P>();
+      constexpr int K1 = F1Slab<NT1, P>::k;
+      const int ks0 = pr.ks0, nslab = (ks0 + K1 - 1) / K1;
+      const float4 z4 = make_float4(0, 0, 0, 0);
+      auto ld = [&](int ks, float4& a, float4& b) {
+        if (ks < ks0) { a = *reinterpret_cast<const float4*>(arow + 16 * ks); b = *reinterpret_cast<const float4*>(arow + 16 * ks + 8); }
+      };
+      auto cvt = [&](int i, const float4& a, const float4& b, FragV<P>& f) {   // pair i of the eight values (a, b)
+        if (i == 0) split_pair<P>(a.x, a.y, cx.a_fwd, 0, f);
+        if (i == 1) split_pair<P>(a.z, a.w, cx.a_fwd, 1, f);
+        if (i == 2) split_pair<P>(b.x, b.y, cx.a_fwd, 2, f);
+        if (i == 3) split_pair<P>(b.z, b.w, cx.a_fwd, 3, f);
+      };
+      float4 c0a = z4, c0b = z4, v1a = z4, v1b = z4, v2a = z4, v2b = z4, w1a = z4, w1b = z4, w2a = z4, w2b = z4;
+      ld(0, c0a, c0b); ld(1, v1a, v1b);
+      if (K1 == 2) ld(2, v2a, v2b);
+      FragV<P> b0, b1, b0n, fa[2];
 #pragma unroll
-        for (int nt = 0; nt < NT1; nt++) {
-          if (nt + 1 < NT1) read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
-          if (nt == 0) split_pair<P>(va.x, va.y, cx.a_fwd, 0, bnxt);
-          if (nt == 1) split_pair<P>(va.z, va.w, cx.a_fwd, 1, bnxt);
-          if (nt == 2) split_pair<P>(vb.x, vb.y, cx.a_fwd, 2, bnxt);
-          if (nt == 3) split_pair<P>(vb.z, vb.w, cx.a_fwd, 3, bnxt);
-          mma_frag<P>(fa[nt & 1], bcur, X1[nt]);
-          if (nt + 1 < NT1) sched_block<P, true>(); else sched_block<P, false>();
+      for (int i = 0; i < 4; i++) cvt(i, c0a, c0b, b0);
+      b1 = b0; b0n = b0;
+      const unsigned char* base = ring_boundary<RING_T, false>(r, ring, min(K1, ks0) * NT1 * P, wave, lane16, cx.err);
+      read_frag<P>(base, 0, fa[0]);
+      sched_first_read<P>();
+      if constexpr (K1 == 2) {
+        for (int kp = 0; kp < nslab; kp++) {
+          const bool two = 2 * kp + 1 < ks0;           // the slab holds two k-steps (all but an odd last one)
+          ld(2 * kp + 3, w1a, w1b); ld(2 * kp + 4, w2a, w2b);
+          // k-step 2 kp: blocks 0 .. NT1 - 1; b1 (k-step 2 kp + 1) is made meanwhile
+#pragma unroll
+          for (int nt = 0; nt < NT1; nt++) {
+            if (nt + 1 < NT1 || two) read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
+            cvt(nt, v1a, v1b, b1);
+            mma_frag<P>(fa[nt & 1], b0, X1[nt]);
+            sched_block<P, true>();
+          }
+          pin<P>(b1);
+          if (two) {
+            // k-step 2 kp + 1: blocks NT1 .. 2 NT1 - 1; b0n (k-step 2 kp + 2) is made meanwhile; the next slab's first
+            // fragments are requested in front of the last block
+#pragma unroll
+            for (int nt = 0; nt < NT1; nt++) {
+              const int j = NT1 + nt;
+              if (nt + 1 < NT1) read_frag<P>(base, j + 1, fa[(j + 1) & 1]);
+              cvt(nt, v2a, v2b, b0n);
+              if (nt + 1 == NT1 && kp + 1 < nslab) {
+                const int nn = min(2, ks0 - 2 * (kp + 1)) * NT1 * P;
+                FUSED_NEXT_SLAB_EARLY(nn, fa[0])      // (j + 1) & 1 == 0: block 0 of the next slab
+                mma_frag<P>(fa[j & 1], b1, X1[nt]);
+                sched_block<P, false>();
+                FUSED_NEXT_SLAB_LATE(nn, fa[0])
+              } else {
+                mma_frag<P>(fa[j & 1], b1, X1[nt]);
+                if (nt + 1 < NT1) sched_block<P, true>(); else sched_block<P, false>();
+              }
+            }
+            pin<P>(b0n);
+          }
+          b0 = b0n;
+          v1a = w1a; v1b = w1b; v2a = w2a; v2b = w2b;
         }
-        pin<P>(bnxt);
-        bcur = bnxt;
-        r.vr += NT1 * P;
+      } else {
+        // one k-step per slab (two of them would not fit the ring three times).  NT1 is even here, so block 0 of every slab
+        // lands in fragment set 0
+        static_assert(K1 == 2 || NT1 % 2 == 0, "fragment sets alternate per block");
+        for (int ks = 0; ks < ks0; ks++) {
+          ld(ks + 2, w1a, w1b);
+#pragma unroll
+          for (int nt = 0; nt < NT1; nt++) {
+            if (nt + 1 < NT1) read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
+            cvt(nt, v1a, v1b, b0n);       // k-step ks + 1
+            if (nt + 1 == NT1 && ks + 1 < ks0) {
+              FUSED_NEXT_SLAB_EARLY(NT1 * P, fa[0])
+              mma_frag<P>(fa[nt & 1], b0, X1[nt]);
+              sched_block<P, false>();
+              FUSED_NEXT_SLAB_LATE(NT1 * P, fa[0])
+            } else {
+              mma_frag<P>(fa[nt & 1], b0, X1[nt]);
+              if (nt + 1 < NT1) sched_block<P, true>(); else sched_block<P, false>();
+            }
+          }
+          pin<P>(b0n);
+          b0 = b0n;
+          v1a = w1a; v1b = w1b;
+        }
       }
     }
     FUSED_STAMP(1);
@@ -493,14 +558,14 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
     // ---- F2, F3 ----
     f32x16 X2[NT2];
     zero_tiles(X2);
-    product_reg<NT1, NT2, NT3, 2 * NT1, NT2, NT1, P>(r, ring, X1, X2, cx.a_fwd, wave, lane16);
+    product_reg<NT1, NT2, NT3, 2 * NT1, NT2, NT1, P>(r, ring, X1, X2, cx.a_fwd, wave, lane16, cx.err);
     FUSED_STAMP(3);
     epilogue_celu(X2, cst + CL::b1, h, inv_f2, cx.alpha, cx.inv_alpha);
     FUSED_STAMP(4);
 
     f32x16 X3[NT3];
     zero_tiles(X3);
-    product_reg<NT1, NT2, NT3, 2 * NT2, NT3, NT2, P>(r, ring, X2, X3, cx.a_fwd, wave, lane16);
+    product_reg<NT1, NT2, NT3, 2 * NT2, NT3, NT2, P>(r, ring, X2, X3, cx.a_fwd, wave, lane16, cx.err);
     FUSED_STAMP(5);
     // last hidden layer fused with the 1-wide output layer and the backward seed dE/dz3 = (1/M) w3 celu'(z3)
     {
@@ -525,49 +590,65 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
 
     FUSED_STAMP(6);
     // ---- B3: g2 = (W2^T g3) celu'(z2), written over h2 ; B2: g1 = (W1^T g2) celu'(z1), written over h1 ----
-    product_inplace<NT1, NT2, NT3, 2 * NT3, NT2, NT3, P>(r, ring, X3, X2, cx.a_bwd, inv_b3, cx.inv_alpha, wave, lane16);
+    product_inplace<NT1, NT2, NT3, 2 * NT3, NT2, NT3, P>(r, ring, X3, X2, cx.a_bwd, inv_b3, cx.inv_alpha, wave, lane16, cx.err);
     FUSED_STAMP(7);
-    product_inplace<NT1, NT2, NT3, 2 * NT2, NT1, NT2, P>(r, ring, X2, X1, cx.a_bwd, inv_b2, cx.inv_alpha, wave, lane16);
+    product_inplace<NT1, NT2, NT3, 2 * NT2, NT1, NT2, P>(r, ring, X2, X1, cx.a_bwd, inv_b2, cx.inv_alpha, wave, lane16, cx.err);
     FUSED_STAMP(8);
     f32x16 (&G1)[NT1] = X1;
 
-    // ---- B1: dE/dAEV = W0^T g1, kChunk 32-column tiles at a time; members after the first add to what is there ----
+    // ---- B1: dE/dAEV = W0^T g1, kChunk 32-column tiles at a time, two k-steps per slab; members after the first add to
+    // what is there ----
     for (int c0 = 0; c0 < pr.nt0; c0 += kChunk) {
       const int ntc = min(kChunk, pr.nt0 - c0);
       f32x16 acc[kChunk];
       zero_tiles(acc);
-      FragV<P> bq[2];
+      FragV<P> bq[2], fa[2];
 #pragma unroll
       for (int i = 0; i < 4; i++) split_pair_of<P>(G1, 0, i, cx.a_bwd, bq[0]);
-#pragma unroll
-      for (int ks = 0; ks < 2 * NT1; ks++) {
-        const unsigned char* base = ring_boundary<RING_T>(r, ring, ntc * P, wave, lane16);
-        FragV<P> fa[2];
+      const unsigned char* base = ring_boundary<RING_T, false>(r, ring, 2 * ntc * P, wave, lane16, cx.err);
+      if (ntc == kChunk) {   // the usual case, free of branches inside a slab
+        constexpr int SB = 2 * kChunk;
         read_frag<P>(base, 0, fa[0]);
         sched_first_read<P>();
-        if (ntc == kChunk) {   // the usual case, free of branches: one scheduling region per k-step
 #pragma unroll
-          for (int t = 0; t < kChunk; t++) {
-            if (t + 1 < kChunk) read_frag<P>(base, t + 1, fa[(t + 1) & 1]);
+        for (int kp = 0; kp < NT1; kp++) {
+#pragma unroll
+          for (int j = 0; j < SB; j++) {
+            const int ks = 2 * kp + j / kChunk, t = j % kChunk, idx = kp * SB + j;
+            if (j + 1 < SB) read_frag<P>(base, j + 1, fa[(idx + 1) & 1]);
             if (ks + 1 < 2 * NT1) split_pair_of<P>(G1, ks + 1, t, cx.a_bwd, bq[(ks + 1) & 1]);
-            mma_frag<P>(fa[t & 1], bq[ks & 1], acc[t]);
-            if (t + 1 < kChunk) sched_block<P, true>(); else sched_block<P, false>();
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < kChunk; t++) {
-            if (t < ntc) {
-              if (t + 1 < ntc) read_frag<P>(base, t + 1, fa[(t + 1) & 1]);
-              mma_frag<P>(fa[t & 1], bq[ks & 1], acc[t]);
+            if (j + 1 == SB && kp + 1 < NT1) {
+              FUSED_NEXT_SLAB_EARLY(SB * P, fa[(idx + 1) & 1])
+              mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[t]);
+              sched_block<P, false>();
+              FUSED_NEXT_SLAB_LATE(SB * P, fa[(idx + 1) & 1])
+            } else {
+              mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[t]);
+              if (j + 1 < SB) sched_block<P, true>(); else sched_block<P, false>();
             }
-          }
-          if (ks + 1 < 2 * NT1) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) split_pair_of<P>(G1, ks + 1, i, cx.a_bwd, bq[(ks + 1) & 1]);
+            if (t == kChunk - 1 && ks + 1 < 2 * NT1) pin<P>(bq[(ks + 1) & 1]);
           }
         }
-        if (ks + 1 < 2 * NT1) pin<P>(bq[(ks + 1) & 1]);
-        r.vr += ntc * P;
+      } else {               // a last, narrower chunk: plain loop, a boundary per slab
+#pragma unroll
+        for (int kp = 0; kp < NT1; kp++) {
+          if (kp > 0) base = ring_boundary<RING_T, false>(r, ring, 2 * ntc * P, wave, lane16, cx.err);
+#pragma unroll
+          for (int s2 = 0; s2 < 2; s2++) {
+            const int ks = 2 * kp + s2;
+#pragma unroll
+            for (int t = 0; t < kChunk; t++) {
+              if (t < ntc) {
+                read_frag<P>(base, s2 * ntc + t, fa[0]);
+                mma_frag<P>(fa[0], bq[ks & 1], acc[t]);
+              }
+            }
+            if (ks + 1 < 2 * NT1) {
+#pragma unroll
+              for (int i = 0; i < 4; i++) split_pair_of<P>(G1, ks + 1, i, cx.a_bwd, bq[(ks + 1) & 1]);
+            }
+          }
+        }
       }
 #pragma unroll
       for (int t = 0; t < kChunk; t++) {
@@ -598,7 +679,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused(FusedArgs G) {
   __shared__ int s_tile;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   TileCtx cx;
-  cx.alpha = G.alpha; cx.inv_alpha = G.inv_alpha; cx.scale = G.scale; cx.M = G.M;
+  cx.alpha = G.alpha; cx.inv_alpha = G.inv_alpha; cx.scale = G.scale; cx.M = G.M; cx.err = G.err_flag;
   cx.a_fwd = P == 2 ? 16.f : 1.f; cx.a_bwd = P == 2 ? 4096.f : 1.f;
   const int total = G.tile_start[G.nprob];
   for (;;) {
