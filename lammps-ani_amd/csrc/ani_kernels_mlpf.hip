@@ -57,7 +57,7 @@ static_assert(kFusedLds + 64 <= 160 * 1024, "ring + constants exceed the LDS of 
 // diagnostic build (-DABLF_STAMPS): wave 0 of every workgroup adds the shader-clock cycles it spent in each phase of a tile
 // to g_fused_stamps (read by ani_debug_fused_stamps); no stamp executes in the shipped kernel
 #ifdef ABLF_STAMPS
-__device__ unsigned long long g_fused_stamps[32];
+__device__ unsigned long long g_fused_stamps[16];
 #define FUSED_STAMP(k)                                                                       \
   do {                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -67,14 +67,6 @@ __device__ unsigned long long g_fused_stamps[32];
     if (wave == 0 && lane == 0) atomicAdd(&g_fused_stamps[k], _t - stamp_prev);              \
     stamp_prev = _t;                                                                         \
   } while (0)
-#define FUSED_BLOCK_STAMP(k)                                                                 \
-  do {                                                                                       \
-    unsigned long long _t;                                                                   \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-    if (wave == 0 && lane16 == 0) atomicAdd(&g_fused_stamps[k], _t - blk_prev);              \
-    blk_prev = _t;                                                                           \
-  } while (0)
 #define FUSED_STAMP_INIT()                                                                   \
   unsigned long long stamp_prev;                                                             \
   do {                                                                                       \
@@ -83,7 +75,6 @@ __device__ unsigned long long g_fused_stamps[32];
     __builtin_amdgcn_sched_barrier(0);                                                       \
   } while (0)
 #else
-#define FUSED_BLOCK_STAMP(k) do {} while (0)
 #define FUSED_STAMP(k) do {} while (0)
 #define FUSED_STAMP_INIT() do {} while (0)
 #endif
@@ -141,63 +132,32 @@ __device__ __forceinline__ void wait_vmcnt_le(int c) {
   else if (c >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-__device__ __forceinline__ void ring_load_piece(const Ring& r, unsigned char* ring, int q0, int pos, int k, int lane16) {
-#ifndef ABLF_NODMA
-  const unsigned char* g = r.src + (size_t)(q0 + k) * 1024 + lane16;
-  unsigned char* l = ring + ((pos + k) << 10);
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-#endif
-}
-// one piece of the slab being dripped (called once per block, between two of its MFMAs)
-__device__ __forceinline__ void ring_drip(Ring& r, unsigned char* ring, int lane16) {
-  if (r.pk < r.pn) {
-    ring_load_piece(r, ring, r.pq0, r.ppos, r.pk, lane16);
-    r.pk += 4;
-  }
-}
-__device__ __forceinline__ void ring_flush(Ring& r, unsigned char* ring, int lane16) {
-  while (r.pk < r.pn) {
-    ring_load_piece(r, ring, r.pq0, r.ppos, r.pk, lane16);
-    r.pk += 4;
-  }
-}
-// refill: every whole slab that fits behind the consumer.  The first becomes the slab that is dripped (whatever was left of
-// the one before has been flushed by the caller); further ones -- at the start of a tile -- are requested at once.
+// refill: every whole slab that fits behind the consumer
 template <int NT1, int NT2, int NT3, int P>
-__device__ __forceinline__ void ring_issue(Ring& r, unsigned char* ring, int wave, int lane16, bool drip) {
+__device__ __forceinline__ void ring_issue(Ring& r, unsigned char* ring, int wave, int lane16) {
   int q0, pos, n;
   while (ring_take<NT1, NT2, NT3, P>(r, wave, q0, pos, n)) {
-    if (drip && r.pk >= r.pn) {
-      r.pq0 = q0; r.ppos = pos; r.pn = n; r.pk = wave;
-    } else {
-      for (int k = wave; k < n; k += 4) ring_load_piece(r, ring, q0, pos, k, lane16);
-    }
+#ifndef ABLF_NODMA
+    const unsigned char* g = r.src + (size_t)q0 * 1024 + lane16;
+    unsigned char* l = ring + (pos << 10);
+    for (int k = wave; k < n; k += 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)k * 1024),
+                                       (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
+#endif
   }
 }
 // In front of a slab of n pieces: returns this lane's read address of the slab's first piece.  EARLY: see ani_fused_ring.h --
 // the call sits in front of the LAST block of the slab before, so that the new slab's first fragments are requested beside
 // that block's MFMAs instead of after them (an LDS round trip with an idle matrix pipe per slab otherwise).
-#ifdef ABLF_STAMPS
-#define RB_STAMP(k) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
-    if (wave == 0 && lane16 == 0) atomicAdd(&g_fused_stamps[k], _t - rb_prev); rb_prev = _t; } while (0)
-#else
-#define RB_STAMP(k) do {} while (0)
-#endif
 template <int NT1, int NT2, int NT3, int P, bool EARLY>
 __device__ __forceinline__ const unsigned char* ring_boundary(Ring& r, unsigned char* ring, int n, int wave, int lane16, int* err_flag) {
-#ifdef ABLF_STAMPS
-  unsigned long long rb_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rb_prev)::"memory");
-#endif
-  ring_flush(r, ring, lane16);   // what the blocks since the last boundary did not get to
-  RB_STAMP(24);
   const int vs = ring_place(r, n);
   if (!EARLY && !ring_issued(r, n)) {
     // rare (ani_fused_ring.h): the slab is not on its way yet.  Every older slab is finished once all waves are here: free
     // the ring, request it, then wait for it like for any other
     asm volatile("s_barrier" ::: "memory");
     ring_before_refill<false>(r, vs);
-    ring_issue<NT1, NT2, NT3, P>(r, ring, wave, lane16, false);
+    ring_issue<NT1, NT2, NT3, P>(r, ring, wave, lane16);
   }
   int allowed = ring_grant(r, n, wave);
   if (allowed < 0 || !(r.qg <= r.qi)) {   // cannot happen (tests/ring_sim.cpp); never silently: the step's energy becomes NaN
@@ -207,19 +167,35 @@ __device__ __forceinline__ const unsigned char* ring_boundary(Ring& r, unsigned 
 #ifndef ABLF_NOWAIT
   wait_vmcnt_le(allowed);
 #endif
-  RB_STAMP(25);
 #ifndef ABLF_NOBAR
   asm volatile("s_barrier" ::: "memory");
 #else
   asm volatile("" ::: "memory");
 #endif
-  RB_STAMP(26);
   ring_before_refill<EARLY>(r, vs);
-  ring_issue<NT1, NT2, NT3, P>(r, ring, wave, lane16, true);
+  ring_issue<NT1, NT2, NT3, P>(r, ring, wave, lane16);
   ring_after_refill(r, vs, n);
-  RB_STAMP(27);
   return ring + (ring_pos(vs) << 10) + lane16;
 }
+// The boundary of a slab that follows another of the same product: early -- in front of the last block of the slab being
+// read, so that the new slab's first fragments are requested beside that block's MFMAs -- if the slab is already on its way,
+// else late, behind that block.  FUSED_NEXT_SLAB_EARLY goes in front of the last block's MFMAs, FUSED_NEXT_SLAB_LATE behind.
+#define FUSED_NEXT_SLAB_EARLY(n_, frag_)                                                            \
+  bool late_ = false;                                                                               \
+  if (ring_can_go_early(r, (n_))) {                                                                 \
+    base = ring_boundary<RING_T, true>(r, ring, (n_), wave, lane16, err);                           \
+    read_frag<P>(base, 0, frag_);                                                                   \
+    sched_first_read<P>();                                                                          \
+  } else {                                                                                          \
+    late_ = true;                                                                                   \
+  }
+#define FUSED_NEXT_SLAB_LATE(n_, frag_)                                                             \
+  if (late_) {                                                                                      \
+    base = ring_boundary<RING_T, false>(r, ring, (n_), wave, lane16, err);                          \
+    read_frag<P>(base, 0, frag_);                                                                   \
+    sched_first_read<P>();                                                                          \
+  }
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int P>
 struct FragV { u32x4 p[P]; };
@@ -256,23 +232,6 @@ __device__ __forceinline__ void mma_frag(const FragV<P>& a, const FragV<P>& b, f
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-  }
-}
-
-// one of a block's MFMAs (P = 3: six, P = 2: three), in the order of mma_frag
-template <int P>
-__device__ __forceinline__ void mma_step(int k, const FragV<P>& a, const FragV<P>& b, f32x16& acc) {
-#ifdef ABLF_NOMMA
-  asm volatile("" ::"v"(a.p[0]), "v"(b.p[0]));
-  return;
-#endif
-  if constexpr (P == 3) {
-    const int pa = k == 0 ? 1 : (k == 1 ? 2 : (k == 3 ? 1 : 0));   // m l h m h h
-    const int pb = k == 0 ? 1 : (k == 2 ? 2 : (k == 4 ? 1 : 0));   // m h l h m h
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[pa]), __builtin_bit_cast(bf16x8, b.p[pb]), acc, 0, 0, 0);
-  } else {
-    const int pa = k == 0 ? 1 : 0, pb = k == 1 ? 1 : 0;            // l h h / h l h
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.p[pa]), __builtin_bit_cast(f16x8, b.p[pb]), acc, 0, 0, 0);
   }
 }
 
@@ -321,34 +280,119 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&X)[NT]) {
 
 #define RING_T NT1, NT2, NT3, P   // the shape parameters the ring's slab sequence depends on
 
-// ---- blocks ----------------------------------------------------------------------------------------------------------
-// A wave is alone on its SIMD and issues in order: vector work hides behind an MFMA only if it stands BETWEEN two MFMAs in
-// the instruction stream -- four or five plain instructions per v_mfma_f32_32x32x16 are free there (tools/mfma_gap_probe2.hip:
-// 32.5 / 33.7 / 39.7 cycles per MFMA with 0 / 4 / 6 fillers), while MFMAs in one bunch and vector work in another simply add
-// up (what the compiler makes of an unconstrained loop: 96 cycles per MFMA).  So the kernel is written as BLOCKS: the P
-// fragment reads of the next block, one block's share of the pending vector work (the epilogue of what an earlier product
-// left in the accumulators and its split into 16-bit terms: about 24 instructions), the block's own 2P MFMAs -- interleaved
-// by sched_group_barrier and fenced from the neighbouring blocks by sched_barrier, so that the compiler can neither bunch
-// the vector work nor sink it to where its result is needed.
+// Order of a block's instructions, pinned (LLVM sched_group_barrier): the P fragment reads of the NEXT block first, then the
+// block's MFMAs one at a time with up to four vector instructions behind each.  A wave issues in order and is alone on its
+// SIMD: left to itself the compiler (short of registers) reads every fragment right in front of the MFMA that needs it
+// -- an LDS round trip per two MFMAs -- and bunches the conversions and epilogues between the MFMA groups, where the matrix
+// pipe waits for them.
 #ifndef ANI_FUSED_VALU_PER_MFMA
 #define ANI_FUSED_VALU_PER_MFMA 4
 #endif
-template <int P, int NREAD>
-__device__ __forceinline__ void block_schedule() {
+template <int P>
+__device__ __forceinline__ void sched_first_read() {   // the slab's first block has nobody to be requested behind
 #ifndef ABLF_NOSCHED
-  if constexpr (NREAD > 0) __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, P, 0);
+#endif
+}
+template <int P, bool READ>
+__device__ __forceinline__ void sched_block() {
+#ifndef ABLF_NOSCHED
+  if constexpr (READ) __builtin_amdgcn_sched_group_barrier(0x100, P, 0);
 #pragma unroll
   for (int i = 0; i < (P == 3 ? 6 : 3); i++) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x002, ANI_FUSED_VALU_PER_MFMA, 0);
   }
-  __builtin_amdgcn_sched_barrier(0);
 #endif
 }
-__device__ __forceinline__ void block_fence() {
-#ifndef ABLF_NOSCHED
-  __builtin_amdgcn_sched_barrier(0);
-#endif
+
+// acc[NT] += W (stream) * X  with X in registers: KS k-steps, two per slab.  The fragments of block i + 1 are requested before
+// the MFMAs of block i (two register sets, statically alternated), across slabs too; the 16-bit terms of k-step ks + 1 are
+// made a pair per block during k-step ks.
+template <int NT1, int NT2, int NT3, int KS, int NT, int NTX, int P>
+__device__ __forceinline__ void product_reg(Ring& r, unsigned char* ring, const f32x16 (&X)[NTX], f32x16 (&acc)[NT], float a_scale,
+                                            int wave, int lane16, int* err) {
+  static_assert(KS <= 2 * NTX && KS % 2 == 0, "k-steps beyond the source tiles");
+  constexpr int SB = 2 * NT;   // blocks per slab
+  FragV<P> bq[2], fa[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) split_pair_of<P>(X, 0, i, a_scale, bq[0]);
+  const unsigned char* base = ring_boundary<RING_T, false>(r, ring, SB * P, wave, lane16, err);
+  read_frag<P>(base, 0, fa[0]);
+  sched_first_read<P>();
+#pragma unroll
+  for (int kp = 0; kp < KS / 2; kp++) {
+#pragma unroll
+    for (int j = 0; j < SB; j++) {
+      const int ks = 2 * kp + j / NT, nt = j % NT, idx = kp * SB + j;
+      const bool next_slab = j + 1 == SB && kp + 1 < KS / 2;
+      if (j + 1 < SB) read_frag<P>(base, j + 1, fa[(idx + 1) & 1]);
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if ((i < NT ? i : NT - 1) == nt) split_pair_of<P>(X, ks + 1, i, a_scale, bq[(ks + 1) & 1]);
+      }
+      if (next_slab) {
+        FUSED_NEXT_SLAB_EARLY(SB * P, fa[(idx + 1) & 1])
+        mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[nt]);
+        sched_block<P, false>();
+        FUSED_NEXT_SLAB_LATE(SB * P, fa[(idx + 1) & 1])
+      } else {
+        mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[nt]);
+        if (j + 1 < SB) sched_block<P, true>(); else sched_block<P, false>();
+      }
+      if (nt == NT - 1 && ks + 1 < KS) pin<P>(bq[(ks + 1) & 1]);
+    }
+  }
+}
+
+// The hidden backward products, in place:  Y[nt] <- (sum_ks W[nt][ks] X[ks]) * inv * celu'(z[nt]),  Y holding the stored
+// activation (through which celu' is known) on entry and the gradient on exit -- no second set of tiles.  The source X is
+// split into its 16-bit terms once (it is dead afterwards: 12 registers per k-step instead of 8), during the first output
+// tile's pass; then one output tile at a time runs through all k-steps on one accumulator (two, alternated: the masking of
+// tile nt - 1 sits among the first MFMAs of tile nt).  A slab is the KS blocks of an output tile.
+template <int NT1, int NT2, int NT3, int KS, int NT, int NTX, int P>
+__device__ __forceinline__ void product_inplace(Ring& r, unsigned char* ring, const f32x16 (&X)[NTX], f32x16 (&Y)[NT], float a_scale,
+                                                float inv, float inv_alpha, int wave, int lane16, int* err) {
+  static_assert(KS <= 2 * NTX, "k-steps beyond the source tiles");
+  FragV<P> bf[KS], fa[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) split_pair_of<P>(X, 0, i, a_scale, bf[0]);
+  f32x16 acc[2];
+  const unsigned char* base = ring_boundary<RING_T, false>(r, ring, KS * P, wave, lane16, err);
+  read_frag<P>(base, 0, fa[0]);
+  sched_first_read<P>();
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[nt & 1][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int idx = nt * KS + ks;
+      const bool next_slab = ks + 1 == KS && nt + 1 < NT;
+      if (ks + 1 < KS) read_frag<P>(base, ks + 1, fa[(idx + 1) & 1]);
+      if (nt == 0 && ks + 1 < KS) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) split_pair_of<P>(X, ks + 1, i, a_scale, bf[ks + 1]);
+      }
+      if (next_slab) {
+        FUSED_NEXT_SLAB_EARLY(KS * P, fa[(idx + 1) & 1])
+        mma_frag<P>(fa[idx & 1], bf[ks], acc[nt & 1]);
+        FUSED_NEXT_SLAB_LATE(KS * P, fa[(idx + 1) & 1])
+      } else {
+        mma_frag<P>(fa[idx & 1], bf[ks], acc[nt & 1]);
+      }
+      if (ks == 1 && nt > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) Y[nt - 1][i] = acc[(nt - 1) & 1][i] * inv * dcelu_from_h(Y[nt - 1][i], inv_alpha);
+      }
+      if (ks + 1 < KS) sched_block<P, true>(); else sched_block<P, false>();
+      if (nt == 0 && ks + 1 < KS) pin<P>(bf[ks + 1]);
+      if (ks == 3 && nt > 0) pin(Y[nt - 1]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) Y[NT - 1][i] = acc[(NT - 1) & 1][i] * inv * dcelu_from_h(Y[NT - 1][i], inv_alpha);
 }
 
 // constants of a member in LDS (floats): b0[32 NT1] b1[32 NT2] b2[32 NT3] w3[32 NT3] then {b3, inv[6]}
@@ -357,239 +401,28 @@ struct ConstLayout {
   static constexpr int b0 = 0, b1 = 32 * NT1, b2 = b1 + 32 * NT2, w3 = b2 + 32 * NT3, tail = w3 + 32 * NT3, count = tail + 8;
 };
 
+template <int NT>
+__device__ __forceinline__ void epilogue_celu(f32x16 (&X)[NT], const float* b, int h, float inv, float alpha, float inv_alpha) {
+#ifdef ABLF_NOEPI   // timing experiment only
+  return;
+#endif
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 bv = *reinterpret_cast<const float4*>(b + 32 * nt + 8 * q + 4 * h);
+      X[nt][4 * q + 0] = celu_f(fmaf(X[nt][4 * q + 0], inv, bv.x), alpha, inv_alpha);
+      X[nt][4 * q + 1] = celu_f(fmaf(X[nt][4 * q + 1], inv, bv.y), alpha, inv_alpha);
+      X[nt][4 * q + 2] = celu_f(fmaf(X[nt][4 * q + 2], inv, bv.z), alpha, inv_alpha);
+      X[nt][4 * q + 3] = celu_f(fmaf(X[nt][4 * q + 3], inv, bv.w), alpha, inv_alpha);
+    }
+}
+
 struct TileCtx {
   float alpha, inv_alpha, scale, a_fwd, a_bwd;
-  float celu_c;   // log2(e) / alpha: celu(z) = z > 0 ? z : alpha exp2(z celu_c) - alpha
   int M;
   int* err;   // device error word (bit 4: the ring schedule broke)
 };
-
-// feature of element j (0..7) of k-step ks held by lane half h: kappa(ks, h, j)
-__device__ __forceinline__ constexpr int kappa0(int ks, int j) { return 16 * ks + 8 * (j >> 2) + (j & 3); }   // + 4 h
-
-// ---- units of pending vector work: one PAIR (elements 2 i, 2 i + 1 of a k-step's fragment) each, cut into SIX stages of
-// four or five instructions: stage s of a block's pair runs behind the block's MFMA s (P = 2: three MFMAs, two stages each) --
-struct PairSt { float t0, t1, u0, u1, x0, x1, r0, r1; unsigned h0, h1; };
-// the split of st.x0, st.x1 (already scaled for P = 2) into word i of every plane: stages 4 and 5 of every kind of pair
-template <int P>
-__device__ __forceinline__ void split_stage(int s, PairSt& st, int i, FragV<P>& f) {
-#ifdef ABLF_NOSPLIT
-  if (s == 5) { for (int p = 0; p < P; p++) f.p[p][i] = __float_as_uint(st.x0); }
-  return;
-#endif
-  if constexpr (P == 3) {
-    if (s == 4) {
-      st.h0 = __float_as_uint(st.x0) & 0xffff0000u; st.h1 = __float_as_uint(st.x1) & 0xffff0000u;
-      st.r0 = st.x0 - __uint_as_float(st.h0); st.r1 = st.x1 - __uint_as_float(st.h1);
-    }
-    if (s == 5) {
-      const unsigned m0 = __float_as_uint(st.r0) & 0xffff0000u, m1 = __float_as_uint(st.r1) & 0xffff0000u;
-      const float l0 = st.r0 - __uint_as_float(m0), l1 = st.r1 - __uint_as_float(m1);
-      f.p[0][i] = pack_hi16(st.h0, st.h1); f.p[1][i] = pack_hi16(m0, m1);
-      f.p[2][i] = pack_hi16(__float_as_uint(l0), __float_as_uint(l1));
-    }
-  } else {
-    if (s == 4) {
-      const f16x2 hv = {(_Float16)st.x0, (_Float16)st.x1};
-      st.h0 = __builtin_bit_cast(unsigned, hv);
-      st.r0 = st.x0 - (float)hv[0]; st.r1 = st.x1 - (float)hv[1];
-    }
-    if (s == 5) {
-      const f16x2 lv = {(_Float16)st.r0, (_Float16)st.r1};
-      f.p[0][i] = st.h0; f.p[1][i] = __builtin_bit_cast(unsigned, lv);
-    }
-  }
-}
-// forward: the pair of k-step ks of X still holds pre-activations z; h = celu(z inv + bias) is written back (the backward
-// pass masks with it) and split into word i of frag
-template <int P, int NTX>
-__device__ __forceinline__ void act_stage(int s, PairSt& st, f32x16 (&X)[NTX], int ks, int i, const float* bias, int h, float inv,
-                                          const TileCtx& cx, FragV<P>& f) {
-  const int t = ks >> 1, e = 8 * (ks & 1) + 2 * i;
-  if (s == 0) {
-    const float2 bv = *reinterpret_cast<const float2*>(bias + kappa0(ks, 2 * i) + 4 * h);
-    st.t0 = fmaf(X[t][e], inv, bv.x); st.t1 = fmaf(X[t][e + 1], inv, bv.y);
-  }
-  if (s == 1) {
-    st.u0 = __builtin_amdgcn_exp2f(st.t0 * cx.celu_c); st.u1 = __builtin_amdgcn_exp2f(st.t1 * cx.celu_c);
-  }
-  if (s == 2) { st.u0 = fmaf(st.u0, cx.alpha, -cx.alpha); st.u1 = fmaf(st.u1, cx.alpha, -cx.alpha); }
-  if (s == 3) {
-    const float h0 = st.t0 > 0.f ? st.t0 : st.u0, h1 = st.t1 > 0.f ? st.t1 : st.u1;
-    X[t][e] = h0; X[t][e + 1] = h1;
-    st.x0 = P == 2 ? h0 * cx.a_fwd : h0; st.x1 = P == 2 ? h1 * cx.a_fwd : h1;
-  }
-  if (s >= 4) split_stage<P>(s, st, i, f);
-}
-template <int P, int NTX>
-__device__ __forceinline__ void act_pair(f32x16 (&X)[NTX], int ks, int i, const float* bias, int h, float inv, const TileCtx& cx,
-                                         FragV<P>& f) {
-  PairSt st;
-#pragma unroll
-  for (int s = 0; s < 6; s++) act_stage<P>(s, st, X, ks, i, bias, h, inv, cx, f);
-}
-// backward: pair q (0..7) of a finished accumulator tile: g = acc inv celu'(z) with z known through the stored activation
-// H; the 16 gradients of a tile are the fragments of two k-steps of the next product: pair q -> word q & 3 of the fragment
-// f of k-step 2 tile + (q >> 2)
-template <int P>
-__device__ __forceinline__ void grad_stage(int s, PairSt& st, const f32x16& acc, const f32x16& H, int q, float inv, const TileCtx& cx,
-                                           FragV<P>& f) {
-  if (s == 0) { st.t0 = acc[2 * q] * (P == 2 ? inv * cx.a_bwd : inv); st.t1 = acc[2 * q + 1] * (P == 2 ? inv * cx.a_bwd : inv); }
-  if (s == 1) { st.u0 = fmaf(H[2 * q], cx.inv_alpha, 1.f); st.u1 = fmaf(H[2 * q + 1], cx.inv_alpha, 1.f); }
-  if (s == 2) { st.u0 = H[2 * q] > 0.f ? 1.f : st.u0; st.u1 = H[2 * q + 1] > 0.f ? 1.f : st.u1; }
-  if (s == 3) { st.x0 = st.t0 * st.u0; st.x1 = st.t1 * st.u1; }
-  if (s >= 4) split_stage<P>(s, st, q & 3, f);
-}
-template <int P>
-__device__ __forceinline__ void grad_pair(const f32x16& acc, const f32x16& H, int q, float inv, const TileCtx& cx, FragV<P>& f) {
-  PairSt st;
-#pragma unroll
-  for (int s = 0; s < 6; s++) grad_stage<P>(s, st, acc, H, q, inv, cx, f);
-}
-// plain values (the AEV rows of the first product): stages 4 and 5 only
-template <int P>
-__device__ __forceinline__ void plain_stage(int s, PairSt& st, float v0, float v1, int i, const TileCtx& cx, FragV<P>& f) {
-  if (s == 3) { st.x0 = P == 2 ? v0 * cx.a_fwd : v0; st.x1 = P == 2 ? v1 * cx.a_fwd : v1; }
-  if (s >= 4) split_stage<P>(s, st, i, f);
-}
-// a block: its 2 P MFMAs, the stages of the pending work (work(s), s = 0..5) behind them one by one, each MFMA and what
-// follows it fenced from the rest
-template <int P, class Work>
-__device__ __forceinline__ void block_mma(Ring& r, unsigned char* ring, int lane16, const FragV<P>& a, const FragV<P>& b, f32x16& acc,
-                                          Work&& work) {
-#pragma clang loop unroll(full)
-  for (int k = 0; k < (P == 3 ? 6 : 3); k++) {
-    mma_step<P>(k, a, b, acc);
-    if (k == 1) ring_drip(r, ring, lane16);   // one weight piece per block, behind an MFMA
-#ifndef ABLF_NOWORK   // timing experiment only: none of the vector work between the MFMAs
-    if constexpr (P == 3) { work(k); } else { work(2 * k); work(2 * k + 1); }
-#endif
-    block_fence();
-  }
-}
-// what a backward product leaves for whoever runs next: its last output tile, not yet masked and split
-struct Pending {
-  f32x16 acc;
-};
-
-// ---- forward product with the source in registers ----------------------------------------------------------------------
-// acc[NT] += W (stream) * celu(X inv_src + bias):  KS k-steps, two per slab.  X holds the PRE-activations of the layer
-// before; the activation of k-step ks + 1, and its 16-bit terms, are made during the blocks of k-step ks, a pair per block.
-template <int NT1, int NT2, int NT3, int KS, int NT, int NTX, int P>
-__device__ __forceinline__ void product_fwd(Ring& r, unsigned char* ring, f32x16 (&X)[NTX], const float* bias, float inv_src,
-                                            f32x16 (&acc)[NT], const TileCtx& cx, int h, int wave, int lane16) {
-  static_assert(KS <= 2 * NTX && KS % 2 == 0, "k-steps beyond the source tiles");
-  constexpr int SB = 2 * NT;   // blocks per slab
-  int* const err = cx.err;
-  FragV<P> bq[2], fa[2];
-#pragma clang loop unroll(full)
-  for (int i = 0; i < 4; i++) act_pair<P>(X, 0, i, bias, h, inv_src, cx, bq[0]);
-  const unsigned char* base = ring_boundary<RING_T, false>(r, ring, SB * P, wave, lane16, err);
-  read_frag<P>(base, 0, fa[0]);
-  block_fence();
-#pragma clang loop unroll(full)
-  for (int kp = 0; kp < KS / 2; kp++) {
-#pragma clang loop unroll(full)
-    for (int j = 0; j < SB; j++) {
-      const int ks = 2 * kp + j / NT, nt = j % NT, idx = kp * SB + j;
-      const bool next_slab = j + 1 == SB && kp + 1 < KS / 2;
-      bool late = false;
-      if (j + 1 < SB) {
-        read_frag<P>(base, j + 1, fa[(idx + 1) & 1]);
-      } else if (next_slab) {
-        if (ring_can_go_early(r, SB * P)) {
-          base = ring_boundary<RING_T, true>(r, ring, SB * P, wave, lane16, err);
-          read_frag<P>(base, 0, fa[(idx + 1) & 1]);
-        } else {
-          late = true;
-        }
-      }
-#ifdef ABLF_STAMPS
-      unsigned long long blk_prev = 0;
-      if (kp == 1 && NT == 6 && KS == 16) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(blk_prev)::"memory"); __builtin_amdgcn_sched_barrier(0); }
-#endif
-      // the pairs of k-step ks + 1 this block makes: pair nt (blocks 0..3); a product of three tiles: pair 3 as well, in block 2
-      PairSt st[2];
-      block_mma<P>(r, ring, lane16, fa[idx & 1], bq[ks & 1], acc[nt], [&](int s) {
-        if (ks + 1 < KS) {
-          if (nt < 4) act_stage<P>(s, st[0], X, ks + 1, nt, bias, h, inv_src, cx, bq[(ks + 1) & 1]);
-          if (NT == 3 && nt == 2) act_stage<P>(s, st[1], X, ks + 1, 3, bias, h, inv_src, cx, bq[(ks + 1) & 1]);
-        }
-      });
-#ifdef ABLF_STAMPS
-      if (kp == 1 && NT == 6 && KS == 16) { FUSED_BLOCK_STAMP(16 + j); }
-#endif
-      if (late) {
-        base = ring_boundary<RING_T, false>(r, ring, SB * P, wave, lane16, err);
-        read_frag<P>(base, 0, fa[(idx + 1) & 1]);
-        block_fence();
-      }
-    }
-  }
-}
-
-// ---- backward product --------------------------------------------------------------------------------------------------
-// out[2 NT] = fragments of  (W (stream) * src) inv celu'(z):  one output tile at a time through all KS k-steps on one
-// accumulator (a slab = the KS blocks of a tile); src[KS] are the 16-bit fragments of the incoming gradient.  The masking and
-// splitting of tile nt's accumulator -- 8 pairs -- is the vector work of tile nt + 1's blocks; the last tile's is handed on
-// (Pending) to the product that follows.  `pend` / Hp / invp: the same for the product before (its last tile).
-// (the pending tile's 16 gradients are the last two k-steps of src itself: KS = 2 NTP)
-template <int NT1, int NT2, int NT3, int KS, int NT, int NTP, int P>
-__device__ __forceinline__ Pending product_bwd(Ring& r, unsigned char* ring, FragV<P> (&src)[KS], const f32x16 (&H)[NT], float inv,
-                                               FragV<P> (&out)[2 * NT], const Pending& pend, const f32x16 (&Hp)[NTP > 0 ? NTP : 1], float invp,
-                                               const TileCtx& cx, int wave, int lane16) {
-  static_assert(NTP == 0 || KS == 2 * NTP, "the pending tile belongs to the product that made src");
-  int* const err = cx.err;
-  FragV<P> fa[2];
-  f32x16 acc[2];
-  acc[1] = pend.acc;   // tile 0 accumulates in acc[0]; the pending tile sits where "tile -1" would
-  const unsigned char* base = ring_boundary<RING_T, false>(r, ring, KS * P, wave, lane16, err);
-  read_frag<P>(base, 0, fa[0]);
-  block_fence();
-#pragma clang loop unroll(full)
-  for (int nt = 0; nt < NT; nt++) {
-#pragma clang loop unroll(full)
-    for (int i = 0; i < 16; i++) acc[nt & 1][i] = 0.f;
-#pragma clang loop unroll(full)
-    for (int ks = 0; ks < KS; ks++) {
-      const int idx = nt * KS + ks;
-      const bool next_slab = ks + 1 == KS && nt + 1 < NT;
-      bool late = false;
-      if (ks + 1 < KS) {
-        read_frag<P>(base, ks + 1, fa[(idx + 1) & 1]);
-      } else if (next_slab) {
-        if (ring_can_go_early(r, KS * P)) {
-          base = ring_boundary<RING_T, true>(r, ring, KS * P, wave, lane16, err);
-          read_frag<P>(base, 0, fa[(idx + 1) & 1]);
-        } else {
-          late = true;
-        }
-      }
-      // this block's share of the tile before: pairs q with q * KS / 8 == ks (KS >= 8: one pair in each of the first 8
-      // blocks; six blocks: two of them take two pairs)
-      PairSt st[2];
-      block_mma<P>(r, ring, lane16, fa[idx & 1], src[ks], acc[nt & 1], [&](int s) {
-        int n = 0;
-#pragma clang loop unroll(full)
-        for (int q = 0; q < 8; q++) {
-          if ((KS >= 8 ? q : q * KS / 8) == ks) {
-            if (nt > 0) grad_stage<P>(s, st[n], acc[(nt - 1) & 1], H[nt - 1], q, inv, cx, out[2 * (nt - 1) + (q >> 2)]);
-            else if (NTP > 0) grad_stage<P>(s, st[n], acc[1], Hp[NTP > 0 ? NTP - 1 : 0], q, invp, cx, src[KS - 2 + (q >> 2)]);
-            n++;
-          }
-        }
-      });
-      if (late) {
-        base = ring_boundary<RING_T, false>(r, ring, KS * P, wave, lane16, err);
-        read_frag<P>(base, 0, fa[(idx + 1) & 1]);
-        block_fence();
-      }
-    }
-  }
-  Pending p;
-  p.acc = acc[(NT - 1) & 1];
-  return p;
-}
 
 // One 128-row tile of a species bucket, all members.  Shape (NT1, NT2, NT3): 32-feature tiles of the three hidden layers
 // (widths padded with zero weights).
@@ -609,7 +442,7 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
   Ring r;
   ring_reset<RING_T>(r, pr.stream, pr.pieces_per_member * cx.M, pr.ks0, pr.nt0);
   FUSED_STAMP_INIT();
-  ring_issue<RING_T>(r, ring, wave, lane16, false);
+  ring_issue<RING_T>(r, ring, wave, lane16);
 
   for (int m = 0; m < cx.M; m++) {
     // the member's constants: one piece per wave, then everything issued so far is waited for (the ring's first slabs among
@@ -628,8 +461,8 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
     const float b3 = cst[CL::tail];
     FUSED_STAMP(0);
 
-    // ---- F1: z1 = W0 aev; the B operand streams from the AEV rows: K1 k-steps (one slab) per iteration, the rows' values
-    // requested a slab ahead, split a pair per block ----
+    // ---- F1: h1 = celu(W0 aev + b0); the B operand streams from the AEV rows: K1 k-steps (one slab) per iteration, the
+    // rows' values requested a slab ahead ----
     f32x16 X1[NT1];
     zero_tiles(X1);
     {
@@ -638,9 +471,6 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
       const float4 z4 = make_float4(0, 0, 0, 0);
       auto ld = [&](int ks, float4& a, float4& b) {
         if (ks < ks0) { a = *reinterpret_cast<const float4*>(arow + 16 * ks); b = *reinterpret_cast<const float4*>(arow + 16 * ks + 8); }
-      };
-      auto pv = [](int i, int w, const float4& a, const float4& b) {   // value w of pair i of the eight values (a, b)
-        return i == 0 ? (w ? a.y : a.x) : (i == 1 ? (w ? a.w : a.z) : (i == 2 ? (w ? b.y : b.x) : (w ? b.w : b.z)));
       };
       auto cvt = [&](int i, const float4& a, const float4& b, FragV<P>& f) {   // pair i of the eight values (a, b)
         if (i == 0) split_pair<P>(a.x, a.y, cx.a_fwd, 0, f);
@@ -652,136 +482,119 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
       ld(0, c0a, c0b); ld(1, v1a, v1b);
       if (K1 == 2) ld(2, v2a, v2b);
       FragV<P> b0, b1, b0n, fa[2];
-#pragma clang loop unroll(full)
+#pragma unroll
       for (int i = 0; i < 4; i++) cvt(i, c0a, c0b, b0);
       b1 = b0; b0n = b0;
-      const unsigned char* base = ring_boundary<RING_T, false>(r, ring, min(K1, ks0) * NT1 * P, wave, lane16, err);
+      const unsigned char* base = ring_boundary<RING_T, false>(r, ring, min(K1, ks0) * NT1 * P, wave, lane16, cx.err);
       read_frag<P>(base, 0, fa[0]);
-      block_fence();
+      sched_first_read<P>();
       if constexpr (K1 == 2) {
         for (int kp = 0; kp < nslab; kp++) {
           const bool two = 2 * kp + 1 < ks0;           // the slab holds two k-steps (all but an odd last one)
           ld(2 * kp + 3, w1a, w1b); ld(2 * kp + 4, w2a, w2b);
           // k-step 2 kp: blocks 0 .. NT1 - 1; b1 (k-step 2 kp + 1) is made meanwhile
-#pragma clang loop unroll(full)
+#pragma unroll
           for (int nt = 0; nt < NT1; nt++) {
             if (nt + 1 < NT1 || two) read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
-            PairSt st;
-            block_mma<P>(r, ring, lane16, fa[nt & 1], b0, X1[nt], [&](int s) { if (nt < 4) plain_stage<P>(s, st, pv(nt, 0, v1a, v1b), pv(nt, 1, v1a, v1b), nt, cx, b1); });
+            cvt(nt, v1a, v1b, b1);
+            mma_frag<P>(fa[nt & 1], b0, X1[nt]);
+            sched_block<P, true>();
           }
+          pin<P>(b1);
           if (two) {
             // k-step 2 kp + 1: blocks NT1 .. 2 NT1 - 1; b0n (k-step 2 kp + 2) is made meanwhile; the next slab's first
             // fragments are requested in front of the last block
-#pragma clang loop unroll(full)
+#pragma unroll
             for (int nt = 0; nt < NT1; nt++) {
               const int j = NT1 + nt;
-              bool late = false;
-              int nn = 0;
-              if (nt + 1 < NT1) {
-                read_frag<P>(base, j + 1, fa[(j + 1) & 1]);
-              } else if (kp + 1 < nslab) {
-                nn = min(2, ks0 - 2 * (kp + 1)) * NT1 * P;
-                if (ring_can_go_early(r, nn)) {
-                  base = ring_boundary<RING_T, true>(r, ring, nn, wave, lane16, err);
-                  read_frag<P>(base, 0, fa[0]);      // (j + 1) & 1 == 0: block 0 of the next slab
-                } else {
-                  late = true;
-                }
-              }
-              PairSt st;
-              block_mma<P>(r, ring, lane16, fa[j & 1], b1, X1[nt], [&](int s) { if (nt < 4) plain_stage<P>(s, st, pv(nt, 0, v2a, v2b), pv(nt, 1, v2a, v2b), nt, cx, b0n); });
-              if (late) {
-                base = ring_boundary<RING_T, false>(r, ring, nn, wave, lane16, err);
-                read_frag<P>(base, 0, fa[0]);
-                block_fence();
+              if (nt + 1 < NT1) read_frag<P>(base, j + 1, fa[(j + 1) & 1]);
+              cvt(nt, v2a, v2b, b0n);
+              if (nt + 1 == NT1 && kp + 1 < nslab) {
+                const int nn = min(2, ks0 - 2 * (kp + 1)) * NT1 * P;
+                FUSED_NEXT_SLAB_EARLY(nn, fa[0])      // (j + 1) & 1 == 0: block 0 of the next slab
+                mma_frag<P>(fa[j & 1], b1, X1[nt]);
+                sched_block<P, false>();
+                FUSED_NEXT_SLAB_LATE(nn, fa[0])
+              } else {
+                mma_frag<P>(fa[j & 1], b1, X1[nt]);
+                if (nt + 1 < NT1) sched_block<P, true>(); else sched_block<P, false>();
               }
             }
+            pin<P>(b0n);
           }
           b0 = b0n;
           v1a = w1a; v1b = w1b; v2a = w2a; v2b = w2b;
         }
       } else {
-        // one k-step per slab (two of them would not fit the ring).  NT1 is even here, so block 0 of every slab lands in
-        // fragment set 0
+        // one k-step per slab (two of them would not fit the ring three times).  NT1 is even here, so block 0 of every slab
+        // lands in fragment set 0
         static_assert(K1 == 2 || NT1 % 2 == 0, "fragment sets alternate per block");
         for (int ks = 0; ks < ks0; ks++) {
           ld(ks + 2, w1a, w1b);
-#pragma clang loop unroll(full)
+#pragma unroll
           for (int nt = 0; nt < NT1; nt++) {
-            bool late = false;
-            if (nt + 1 < NT1) {
-              read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
-            } else if (ks + 1 < ks0) {
-              if (ring_can_go_early(r, NT1 * P)) {
-                base = ring_boundary<RING_T, true>(r, ring, NT1 * P, wave, lane16, err);
-                read_frag<P>(base, 0, fa[0]);
-              } else {
-                late = true;
-              }
-            }
-            PairSt st;                    // b0n: k-step ks + 1
-            block_mma<P>(r, ring, lane16, fa[nt & 1], b0, X1[nt], [&](int s) { if (nt < 4) plain_stage<P>(s, st, pv(nt, 0, v1a, v1b), pv(nt, 1, v1a, v1b), nt, cx, b0n); });
-            if (late) {
-              base = ring_boundary<RING_T, false>(r, ring, NT1 * P, wave, lane16, err);
-              read_frag<P>(base, 0, fa[0]);
-              block_fence();
+            if (nt + 1 < NT1) read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
+            cvt(nt, v1a, v1b, b0n);       // k-step ks + 1
+            if (nt + 1 == NT1 && ks + 1 < ks0) {
+              FUSED_NEXT_SLAB_EARLY(NT1 * P, fa[0])
+              mma_frag<P>(fa[nt & 1], b0, X1[nt]);
+              sched_block<P, false>();
+              FUSED_NEXT_SLAB_LATE(NT1 * P, fa[0])
+            } else {
+              mma_frag<P>(fa[nt & 1], b0, X1[nt]);
+              if (nt + 1 < NT1) sched_block<P, true>(); else sched_block<P, false>();
             }
           }
+          pin<P>(b0n);
           b0 = b0n;
           v1a = w1a; v1b = w1b;
         }
       }
     }
     FUSED_STAMP(1);
+    epilogue_celu(X1, cst + CL::b0, h, inv_f1, cx.alpha, cx.inv_alpha);
+    FUSED_STAMP(2);
 
-    // ---- F2: z2 = W1 celu(z1 + b0) ; F3: z3 = W2 celu(z2 + b1).  After each, the source tiles hold the activations ----
+    // ---- F2, F3 ----
     f32x16 X2[NT2];
     zero_tiles(X2);
-    product_fwd<NT1, NT2, NT3, 2 * NT1, NT2, NT1, P>(r, ring, X1, cst + CL::b0, inv_f1, X2, cx, h, wave, lane16);
+    product_reg<NT1, NT2, NT3, 2 * NT1, NT2, NT1, P>(r, ring, X1, X2, cx.a_fwd, wave, lane16, cx.err);
     FUSED_STAMP(3);
+    epilogue_celu(X2, cst + CL::b1, h, inv_f2, cx.alpha, cx.inv_alpha);
+    FUSED_STAMP(4);
+
     f32x16 X3[NT3];
     zero_tiles(X3);
-    product_fwd<NT1, NT2, NT3, 2 * NT2, NT3, NT2, P>(r, ring, X2, cst + CL::b1, inv_f2, X3, cx, h, wave, lane16);
+    product_reg<NT1, NT2, NT3, 2 * NT2, NT3, NT2, P>(r, ring, X2, X3, cx.a_fwd, wave, lane16, cx.err);
     FUSED_STAMP(5);
-
-    // ---- last hidden layer, the 1-wide output layer and the backward seed dE/dz3 = (1/M) w3 celu'(z3), split at once into
-    // the fragments the first backward product multiplies ----
-    FragV<P> bf3[2 * NT3];
+    // last hidden layer fused with the 1-wide output layer and the backward seed dE/dz3 = (1/M) w3 celu'(z3)
     {
       float es = 0.f;
-#pragma clang loop unroll(full)
-      for (int ks = 0; ks < 2 * NT3; ks++)
-#pragma clang loop unroll(full)
-        for (int i = 0; i < 4; i++) {
-          const int t = ks >> 1, e = 8 * (ks & 1) + 2 * i;
-          const float2 bv = *reinterpret_cast<const float2*>(cst + CL::b2 + kappa0(ks, 2 * i) + 4 * h);
-          const float2 wv = *reinterpret_cast<const float2*>(cst + CL::w3 + kappa0(ks, 2 * i) + 4 * h);
-          const float h0 = celu_f(fmaf(X3[t][e], inv_f3, bv.x), cx.alpha, cx.inv_alpha);
-          const float h1 = celu_f(fmaf(X3[t][e + 1], inv_f3, bv.y), cx.alpha, cx.inv_alpha);
-          es = fmaf(h0, wv.x, es);
-          es = fmaf(h1, wv.y, es);
-          split_pair<P>(valid * wv.x * dcelu_from_h(h0, cx.inv_alpha), valid * wv.y * dcelu_from_h(h1, cx.inv_alpha), cx.a_bwd, i, bf3[ks]);
+#pragma unroll
+      for (int nt = 0; nt < NT3; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 bv = *reinterpret_cast<const float4*>(cst + CL::b2 + 32 * nt + 8 * q + 4 * h);
+          const float4 wv = *reinterpret_cast<const float4*>(cst + CL::w3 + 32 * nt + 8 * q + 4 * h);
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float hv = celu_f(fmaf(X3[nt][4 * q + i], inv_f3, bb[i]), cx.alpha, cx.inv_alpha);
+            es = fmaf(hv, ww[i], es);
+            X3[nt][4 * q + i] = valid * ww[i] * dcelu_from_h(hv, cx.inv_alpha);
+          }
         }
       es += __shfl_xor(es, 32);
       if (h == 0) pr.e_rows[(size_t)m * pr.sE + row] = valid * (es + b3);
     }
-    FUSED_STAMP(6);
 
-    // ---- B3: g2 = (W2^T g3) celu'(z2) ; B2: g1 = (W1^T g2) celu'(z1): each gradient leaves its product as fragments ----
-    FragV<P> bf2[2 * NT2], bf1[2 * NT1];
-    Pending none;
-#pragma clang loop unroll(full)
-    for (int i = 0; i < 16; i++) none.acc[i] = 0.f;
-    f32x16 nohp[1];
-#pragma clang loop unroll(full)
-    for (int i = 0; i < 16; i++) nohp[0][i] = 0.f;
-    const Pending p3 = product_bwd<NT1, NT2, NT3, 2 * NT3, NT2, 0, P>(r, ring, bf3, X2, inv_b3, bf2, none, nohp, 0.f, cx, wave, lane16);
+    FUSED_STAMP(6);
+    // ---- B3: g2 = (W2^T g3) celu'(z2), written over h2 ; B2: g1 = (W1^T g2) celu'(z1), written over h1 ----
+    product_inplace<NT1, NT2, NT3, 2 * NT3, NT2, NT3, P>(r, ring, X3, X2, cx.a_bwd, inv_b3, cx.inv_alpha, wave, lane16, cx.err);
     FUSED_STAMP(7);
-    const Pending p2 = product_bwd<NT1, NT2, NT3, 2 * NT2, NT1, NT2, P>(r, ring, bf2, X1, inv_b2, bf1, p3, X2, inv_b3, cx, wave, lane16);
+    product_inplace<NT1, NT2, NT3, 2 * NT2, NT1, NT2, P>(r, ring, X2, X1, cx.a_bwd, inv_b2, cx.inv_alpha, wave, lane16, cx.err);
     FUSED_STAMP(8);
-    // the last tile of g1 (B1's first blocks would be the place to hide it; it is 8 pairs)
-#pragma clang loop unroll(full)
-    for (int q = 0; q < 8; q++) grad_pair<P>(p2.acc, X1[NT1 - 1], q, inv_b2, cx, bf1[2 * (NT1 - 1) + (q >> 2)]);
+    f32x16 (&G1)[NT1] = X1;
 
     // ---- B1: dE/dAEV = W0^T g1, kChunk 32-column tiles at a time, two k-steps per slab; members after the first add to
     // what is there ----
@@ -789,56 +602,58 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
       const int ntc = min(kChunk, pr.nt0 - c0);
       f32x16 acc[kChunk];
       zero_tiles(acc);
-      FragV<P> fa[2];
-      const unsigned char* base = ring_boundary<RING_T, false>(r, ring, 2 * ntc * P, wave, lane16, err);
+      FragV<P> bq[2], fa[2];
+#pragma unroll
+      for (int i = 0; i < 4; i++) split_pair_of<P>(G1, 0, i, cx.a_bwd, bq[0]);
+      const unsigned char* base = ring_boundary<RING_T, false>(r, ring, 2 * ntc * P, wave, lane16, cx.err);
       if (ntc == kChunk) {   // the usual case, free of branches inside a slab
         constexpr int SB = 2 * kChunk;
         read_frag<P>(base, 0, fa[0]);
-        block_fence();
-#pragma clang loop unroll(full)
+        sched_first_read<P>();
+#pragma unroll
         for (int kp = 0; kp < NT1; kp++) {
-#pragma clang loop unroll(full)
+#pragma unroll
           for (int j = 0; j < SB; j++) {
             const int ks = 2 * kp + j / kChunk, t = j % kChunk, idx = kp * SB + j;
-            bool late = false;
-            if (j + 1 < SB) {
-              read_frag<P>(base, j + 1, fa[(idx + 1) & 1]);
-            } else if (kp + 1 < NT1) {
-              if (ring_can_go_early(r, SB * P)) {
-                base = ring_boundary<RING_T, true>(r, ring, SB * P, wave, lane16, err);
-                read_frag<P>(base, 0, fa[(idx + 1) & 1]);
-              } else {
-                late = true;
-              }
+            if (j + 1 < SB) read_frag<P>(base, j + 1, fa[(idx + 1) & 1]);
+            if (ks + 1 < 2 * NT1) split_pair_of<P>(G1, ks + 1, t, cx.a_bwd, bq[(ks + 1) & 1]);
+            if (j + 1 == SB && kp + 1 < NT1) {
+              FUSED_NEXT_SLAB_EARLY(SB * P, fa[(idx + 1) & 1])
+              mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[t]);
+              sched_block<P, false>();
+              FUSED_NEXT_SLAB_LATE(SB * P, fa[(idx + 1) & 1])
+            } else {
+              mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[t]);
+              if (j + 1 < SB) sched_block<P, true>(); else sched_block<P, false>();
             }
-            block_mma<P>(r, ring, lane16, fa[idx & 1], bf1[ks], acc[t], [](int) {});
-            if (late) {
-              base = ring_boundary<RING_T, false>(r, ring, SB * P, wave, lane16, err);
-              read_frag<P>(base, 0, fa[(idx + 1) & 1]);
-              block_fence();
-            }
+            if (t == kChunk - 1 && ks + 1 < 2 * NT1) pin<P>(bq[(ks + 1) & 1]);
           }
         }
       } else {               // a last, narrower chunk: plain loop, a boundary per slab
-#pragma clang loop unroll(full)
+#pragma unroll
         for (int kp = 0; kp < NT1; kp++) {
-          if (kp > 0) base = ring_boundary<RING_T, false>(r, ring, 2 * ntc * P, wave, lane16, err);
-#pragma clang loop unroll(full)
+          if (kp > 0) base = ring_boundary<RING_T, false>(r, ring, 2 * ntc * P, wave, lane16, cx.err);
+#pragma unroll
           for (int s2 = 0; s2 < 2; s2++) {
-#pragma clang loop unroll(full)
+            const int ks = 2 * kp + s2;
+#pragma unroll
             for (int t = 0; t < kChunk; t++) {
               if (t < ntc) {
                 read_frag<P>(base, s2 * ntc + t, fa[0]);
-                mma_frag<P>(fa[0], bf1[2 * kp + s2], acc[t]);
+                mma_frag<P>(fa[0], bq[ks & 1], acc[t]);
               }
+            }
+            if (ks + 1 < 2 * NT1) {
+#pragma unroll
+              for (int i = 0; i < 4; i++) split_pair_of<P>(G1, ks + 1, i, cx.a_bwd, bq[(ks + 1) & 1]);
             }
           }
         }
       }
-#pragma clang loop unroll(full)
+#pragma unroll
       for (int t = 0; t < kChunk; t++) {
         if (t < ntc) {
-#pragma clang loop unroll(full)
+#pragma unroll
           for (int q = 0; q < 4; q++) {
             const int f0 = 32 * (c0 + t) + 8 * q;   // + 4 h is in grow
             if (f0 + 4 * h < pr.acols) {
@@ -866,7 +681,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused(FusedArgs G) {
   TileCtx cx;
   cx.alpha = G.alpha; cx.inv_alpha = G.inv_alpha; cx.scale = G.scale; cx.M = G.M; cx.err = G.err_flag;
   cx.a_fwd = P == 2 ? 16.f : 1.f; cx.a_bwd = P == 2 ? 4096.f : 1.f;
-  cx.celu_c = G.inv_alpha * 1.4426950408889634f;
   const int total = G.tile_start[G.nprob];
   for (;;) {
     __syncthreads();   // every wave is done with the tile before (ring, constants, s_tile)
@@ -905,11 +719,11 @@ long long fused_pieces_per_member(int shape, int acols, int P) {
   return P * (ks0 * s[0] + 2LL * s[0] * s[1] + 2LL * s[1] * s[2] + 2LL * s[2] * s[1] + 2LL * s[1] * s[0] + 2LL * s[0] * nt0);
 }
 
-int fused_read_stamps(unsigned long long* out16, int reset) {   // 32 slots
+int fused_read_stamps(unsigned long long* out16, int reset) {
 #ifdef ABLF_STAMPS
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[16] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 1;
