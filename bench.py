@@ -259,8 +259,13 @@ def main():
         apply_env_options(ani)
         if args.dense_aev:
             ani.set_option("prune_absent_species", 0)
+        # several ranks over RCCL: the exchanges run inside libani_hip.so (include/ani_comm.h: grouped ncclSend / ncclRecv on
+        # the compute stream); ANI_BENCH_NATIVE_COMM=0 keeps them on torch.distributed's all_to_all_single for comparison
+        native = None
+        if world > 1 and backend == "nccl" and os.environ.get("ANI_BENCH_NATIVE_COMM", "1") not in ("", "0"):
+            native = ani_hip.NativeComm.from_torch(dev_index)
         run = md.VerletRun(ani, inp, system.boxhi - system.boxlo, dev, dt=0.5, langevin=(300.0, 100.0), box_lo=system.boxlo, grid=grid,
-                           overlap=True if args.overlap else None)
+                           overlap=True if args.overlap else None, native_comm=native)
         parity = None
         if with_parity and world == 1:
             # the MD pass runs on its own model file (output layer scaled): its forces at the start structure against the
@@ -303,6 +308,8 @@ def main():
         info = {"steps": steps, "ms_per_step": dt / steps * 1e3, "list_rebuilds": run.nbuilds - b0,
                 "npairs_rank0": run.npairs, "nlocal_rank0": run.nlocal, "nghost_rank0": run.ntotal - run.nlocal,
                 "temperature_K": 2.0 * ke / (3.0 * natoms_all - 3.0) / md.BOLTZ, "exchange_overlap": bool(run._overlap),
+                "exchange": None if world == 1 else ("ani_comm: grouped ncclSend/ncclRecv inside libani_hip.so" if native is not None else
+                                                     f"torch.distributed all_to_all_single ({backend})"),
                 "energy_finite": bool(np.isfinite(run.potential_energy())), "model_out_scale": MD_OUT_SCALE,
                 "mlp_arith": arith if arith is not None else 1}
         if parity:
@@ -330,6 +337,8 @@ def main():
             info["energy_finite"] = info["energy_finite"] and bool(np.isfinite(run.potential_energy()))
         view = ani.debug_view()
         ani.close()
+        if native is not None:
+            native.close()
         return dt, ph, info, view.aev_active_length
 
     # ---- hot path on static positions (phase times for the secondary numbers, parity against the oracle) -------------

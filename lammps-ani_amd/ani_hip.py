@@ -23,6 +23,11 @@ EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani
            "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times",
            "ani_trace_push", "ani_trace_pop", "ani_trace_mark", "ani_step_begin", "ani_step_ghosts_ready", "ani_step_finish",
            "ani_debug_fused_stamps"]
+# include/ani_comm.h: the device-side ghost exchange over RCCL
+COMM_EXPORTS = ["ani_comm_get_unique_id", "ani_comm_create", "ani_comm_destroy", "ani_comm_last_error", "ani_comm_rank",
+                "ani_comm_size", "ani_comm_plan", "ani_comm_exchange_counts", "ani_comm_alltoallv", "ani_comm_set_epoch",
+                "ani_comm_forward", "ani_comm_reverse", "ani_comm_reverse_send", "ani_comm_reverse_unpack",
+                "ani_comm_allreduce_f64", "ani_comm_set_option"]
 
 
 class AniError(RuntimeError):
@@ -98,6 +103,24 @@ def lib():
         L.ani_md_reverse_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ani_md_pack_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ani_md_unpack_reverse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        # include/ani_comm.h
+        L.ani_comm_get_unique_id.argtypes = [C.c_void_p]
+        L.ani_comm_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ani_comm_destroy.argtypes = [C.c_void_p]
+        L.ani_comm_last_error.restype = C.c_char_p
+        L.ani_comm_last_error.argtypes = [C.c_void_p]
+        L.ani_comm_rank.argtypes = [C.c_void_p]
+        L.ani_comm_size.argtypes = [C.c_void_p]
+        L.ani_comm_plan.argtypes = [C.c_int] + [C.c_void_p] * 6
+        L.ani_comm_exchange_counts.argtypes = [C.c_void_p] * 4
+        L.ani_comm_alltoallv.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        L.ani_comm_set_epoch.argtypes = [C.c_void_p] * 5
+        L.ani_comm_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ani_comm_reverse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ani_comm_reverse_send.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ani_comm_reverse_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ani_comm_allreduce_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ani_comm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.ani_phase_timing.argtypes = [C.c_void_p, C.c_int]
         L.ani_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _lib = L
@@ -240,3 +263,100 @@ class ANI:
         n = C.c_int()
         self._check(self._lib.ani_phase_times(self._h, ms, C.byref(n)))
         return dict(aev_fwd=ms[0], mlp=ms[1], aev_bwd=ms[2], other=ms[3], compact=ms[4], calls=n.value)
+
+
+def comm_plan(send_counts, recv_counts):
+    """ani_comm_plan: (send_off, recv_off, nsend, nrecv) of an all-to-all with these per-peer counts.  Host arithmetic
+    only: works without a GPU."""
+    sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+    rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+    so, ro = np.zeros_like(sc), np.zeros_like(rc)
+    ns, nr = C.c_int64(), C.c_int64()
+    if lib().ani_comm_plan(len(sc), sc.ctypes.data, rc.ctypes.data, so.ctypes.data, ro.ctypes.data, C.addressof(ns), C.addressof(nr)) != 0:
+        raise AniError("ani_comm_plan: bad counts")
+    return so, ro, ns.value, nr.value
+
+
+class NativeComm:
+    """include/ani_comm.h: the ghost exchange between ranks as grouped ncclSend / ncclRecv inside libani_hip.so (no torch on
+    the data path).  ``id_bytes``: the 128 bytes rank 0 got from ``NativeComm.unique_id()``, handed to every rank by the
+    caller (``from_torch`` does it with torch.distributed, the python loop's bootstrap)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        if lib().ani_comm_get_unique_id(buf) != 0:
+            raise AniError("ani_comm_get_unique_id: " + lib().ani_comm_last_error(None).decode())
+        return bytes(buf)
+
+    @classmethod
+    def from_torch(cls, device_index: int, group=None):
+        """bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast as an object"""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        return cls(world, rank, box[0], device_index)
+
+    def __init__(self, nranks: int, rank: int, id_bytes: bytes, device_index: int = 0):
+        self._lib = lib()
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(id_bytes, 128)
+        rc = self._lib.ani_comm_create(nranks, rank, buf, device_index, C.byref(self._h))
+        if rc != 0:
+            raise AniError(f"ani_comm_create failed ({rc}): {self._lib.ani_comm_last_error(None).decode()}")
+        self.world, self.rank = nranks, rank
+        self._keep = ()
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ani_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AniError(f"ani_comm error {rc}: {self._lib.ani_comm_last_error(self._h).decode()}")
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.ani_comm_set_option(self._h, name.encode(), int(value)))
+
+    def exchange_counts(self, send_counts, stream=None):
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.zeros_like(sc)
+        self._check(self._lib.ani_comm_exchange_counts(self._h, sc.ctypes.data, rc.ctypes.data, stream))
+        return rc.tolist()
+
+    def alltoallv(self, d_send, send_counts, d_recv, recv_counts, item_bytes: int, stream=None):
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        self._check(self._lib.ani_comm_alltoallv(self._h, d_send, sc.ctypes.data, d_recv, rc.ctypes.data, int(item_bytes), stream))
+
+    def set_epoch(self, send_counts, recv_counts, send_idx, send_shift):
+        """send_idx (int64) / send_shift (float64 [n,3]): device tensors; kept alive here until the next epoch"""
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        self._keep = (send_idx, send_shift)
+        self._check(self._lib.ani_comm_set_epoch(self._h, sc.ctypes.data, rc.ctypes.data, send_idx.data_ptr(), send_shift.data_ptr()))
+
+    def forward(self, d_x, nlocal: int, stream=None):
+        self._check(self._lib.ani_comm_forward(self._h, d_x, nlocal, stream))
+
+    def reverse(self, d_f, nlocal: int, stream=None):
+        self._check(self._lib.ani_comm_reverse(self._h, d_f, nlocal, stream))
+
+    def reverse_send(self, d_f, nlocal: int, stream=None):
+        self._check(self._lib.ani_comm_reverse_send(self._h, d_f, nlocal, stream))
+
+    def reverse_unpack(self, d_f, stream=None):
+        self._check(self._lib.ani_comm_reverse_unpack(self._h, d_f, stream))
+
+    def allreduce(self, d_buf, n: int, op: str = "sum", stream=None):
+        self._check(self._lib.ani_comm_allreduce_f64(self._h, d_buf, n, 0 if op == "sum" else 1, stream))

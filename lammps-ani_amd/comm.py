@@ -132,10 +132,18 @@ class DomainComm:
     Layout after ``borders``: ``x[:nlocal]`` owned atoms, ``x[nlocal:]`` ghosts in arrival order.
     """
 
-    def __init__(self, grid, box_lo, box_len, cutghost, device, group=None, periodic=(True, True, True)):
+    def __init__(self, grid, box_lo, box_len, cutghost, device, group=None, periodic=(True, True, True), native=None,
+                 force_collectives=False):
+        """native: an ani_hip.NativeComm (include/ani_comm.h) -- every message then travels as grouped ncclSend / ncclRecv
+        inside libani_hip.so instead of torch.distributed collectives (device arrays only); force_collectives: a single rank
+        takes the several-rank code paths (collectives with one participant) -- what lets one GPU exercise them."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.native = native
+        if native is not None:
+            assert (native.world, native.rank) == (self.world, self.rank), "the native communicator spans other ranks"
+        self.multi = self.world > 1 or bool(force_collectives)
         px, py, pz = grid
         assert px * py * pz == self.world, (grid, self.world)
         self.grid = (px, py, pz)
@@ -146,7 +154,8 @@ class DomainComm:
         self.len_np = np.asarray(box_len, dtype=np.float64)
         self.box_lo = torch.as_tensor(self.lo_np, device=device)
         self.box_len = torch.as_tensor(self.len_np, device=device)
-        self.host_staged = (self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda")
+        self.host_staged = (native is None and self.world > 1 and dist.get_backend(group) == "gloo" and
+                            torch.device(device).type == "cuda")
         r = self.rank
         self.me = (r % px, (r // px) % py, r // (px * py))   # harness/lmp_harness.cpp: rank = ix + px*(iy + py*iz)
         P = np.array(self.grid, dtype=np.float64)
@@ -192,19 +201,30 @@ class DomainComm:
     # ---- plumbing -----------------------------------------------------------------------------------------------
     def _counts(self, send_counts):
         """exchange per-peer message sizes (one host round trip; rebuild steps only)"""
-        if self.world == 1:
+        if not self.multi:
             return list(send_counts)
+        if self.native is not None:
+            return self.native.exchange_counts(send_counts, stream=self._stream())
         sc = torch.as_tensor(send_counts, dtype=torch.int64, device="cpu" if self.host_staged or dist.get_backend(self.group) == "gloo" else self.device)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)
         return rc.cpu().tolist()
 
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream if torch.device(self.device).type == "cuda" else None
+
     def _a2a(self, inp, out_splits, in_splits, out=None):
         """out: optional contiguous destination (e.g. the ghost block of the position array: received in place)"""
         if out is None:
             out = torch.empty((int(sum(out_splits)),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
-        if self.world == 1:
+        if not self.multi:
             out.copy_(inp)
+        elif self.native is not None:
+            inp = inp.contiguous()
+            assert out.is_contiguous()
+            item = inp.element_size() * int(np.prod(inp.shape[1:], dtype=np.int64))
+            self.native.alltoallv(inp.data_ptr(), in_splits, out.data_ptr(), out_splits, item, stream=self._stream())
+            self._inflight = inp   # the send buffer must outlive the enqueued transfer (stream-ordered allocator: same stream)
         elif self.host_staged:
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(o, inp.cpu().contiguous(), out_splits, in_splits, group=self.group)
@@ -228,7 +248,7 @@ class DomainComm:
                 if self.periodic[d]:
                     x[:, d] -= torch.floor((x[:, d] - lo[d]) / L[d]) * L[d]
                     x[:, d] = torch.where(x[:, d] >= lo[d] + L[d], lo[d], x[:, d])
-        if self.world == 1:
+        if not self.multi:
             return (x,) + tuple(per_atom)
         P = torch.tensor(self.grid, dtype=torch.float64, device=x.device)
         b = torch.floor((x - lo) / L * P).long()
@@ -264,6 +284,9 @@ class DomainComm:
         self.recv_splits = self._counts(send)
         self.nlocal = n
         self.nghost = int(sum(self.recv_splits))
+        if self.native is not None:
+            self.send_shift = self.send_shift.contiguous()
+            self.native.set_epoch(self.send_splits, self.recv_splits, self.send_idx, self.send_shift)
         gx = self._a2a(x[self.send_idx] + self.send_shift, self.recv_splits, self.send_splits)
         gs = self._a2a(species[self.send_idx], self.recv_splits, self.send_splits)
         return torch.cat([x, gx]).contiguous(), torch.cat([species, gs]).contiguous()
@@ -273,8 +296,11 @@ class DomainComm:
         """x: [nlocal + nghost, 3]; refreshes the ghost block from the owners' current positions."""
         if self.nghost == 0 and self.send_idx.numel() == 0:
             return
+        if self.native is not None and self.multi:
+            self.native.forward(x.data_ptr(), self.nlocal, stream=self._stream())
+            return
         msg = x[: self.nlocal][self.send_idx] + self.send_shift
-        if self.world == 1:
+        if not self.multi:
             x[self.nlocal:] = msg
         else:
             x[self.nlocal:] = self._a2a(msg, self.recv_splits, self.send_splits)
@@ -283,7 +309,10 @@ class DomainComm:
         """f: [nlocal + nghost, 3]; adds every ghost's force into its owner's row (on whichever rank that is)."""
         if self.nghost == 0 and self.send_idx.numel() == 0:
             return
+        if self.native is not None and self.multi:
+            self.native.reverse(f.data_ptr(), self.nlocal, stream=self._stream())
+            return
         g = f[self.nlocal:]
-        if self.world > 1:
+        if self.multi:
             g = self._a2a(g, self.send_splits, self.recv_splits)
         f[: self.nlocal].index_add_(0, self.send_idx, g)

@@ -37,7 +37,8 @@ ANI2X_MASSES = (1.008, 12.011, 14.007, 15.999, 32.06, 18.998, 35.45)
 class VerletRun:
     def __init__(self, ani, inp, box_len, device, dt: float = 0.5, cutoff: float = 5.1, skin: float = 2.0,
                  ghost_margin: float = 0.0, every: int = 10, masses=ANI2X_MASSES, group=None, seed: int = 12345,
-                 langevin=None, box_lo=None, grid=None, periodic=(True, True, True), overlap=None):
+                 langevin=None, box_lo=None, grid=None, periodic=(True, True, True), overlap=None, native_comm=None,
+                 force_collectives=False):
         """ani: ani_hip.ANI (full list, any precision); inp: harness.RankInput of this rank — only its OWNED atoms
         (positions, types, global tags) are taken, ghosts and lists are rebuilt here; langevin: None or
         (T_target, damp_fs) as ``fix langevin T T damp seed``; grid: processor grid (default comm.grid_for(world));
@@ -45,7 +46,10 @@ class VerletRun:
         exchanges of a step on a second stream beside the rows that do not need them (the library's split step,
         include/ani_hip.h ani_step_*).  Cutting the step costs five more launches (+0.05 ms at 12 500 atoms per GPU,
         measured on one card), which the hidden exchanges have to pay back: default on with several ranks over RCCL (two
-        latency-bound all-to-alls per step), off otherwise; environment ANI_MD_OVERLAP=0/1 overrides the default."""
+        latency-bound all-to-alls per step), off otherwise; environment ANI_MD_OVERLAP=0/1 overrides the default.
+        native_comm: an ani_hip.NativeComm -- the exchanges then run inside libani_hip.so as grouped ncclSend / ncclRecv
+        (include/ani_comm.h) instead of torch.distributed collectives; force_collectives: a single rank takes the several-rank
+        paths (one-participant collectives), so that one GPU can exercise them."""
         from .comm import DomainComm, grid_for
         self.ani, self.device, self.group = ani, device, group
         world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -53,7 +57,9 @@ class VerletRun:
         box_lo = np.zeros(3) if box_lo is None else np.asarray(box_lo, dtype=np.float64)
         self._box_lo_np = box_lo
         self._box_len_np = np.asarray(box_len, dtype=np.float64)
-        self.dc = DomainComm(grid or grid_for(world), box_lo, box_len, self.cutneigh, device, group=group, periodic=periodic)
+        self.dc = DomainComm(grid or grid_for(world), box_lo, box_len, self.cutneigh, device, group=group, periodic=periodic,
+                             native=native_comm, force_collectives=force_collectives)
+        self.native = native_comm
         self.ex = self.dc   # the exchange object (forward_positions / reverse_add)
         self.masses = torch.as_tensor(np.asarray(masses, dtype=np.float64), device=device)
         self.langevin = langevin
@@ -83,8 +89,8 @@ class VerletRun:
             self._recvbuf = torch.empty((0, 3), dtype=torch.float64, device=device)
             ani.set_option("device_overwrite_forces", 1)   # no separate force_clear launch
         env = os.environ.get("ANI_MD_OVERLAP")
-        nccl = world > 1 and dist.get_backend(group) == "nccl"
-        want = nccl if overlap is None else bool(overlap)
+        # default off: cutting the step costs +0.05 ms on one card and its benefit has not been measured on several
+        want = False if overlap is None else bool(overlap)
         if env is not None and overlap is None:
             want = env not in ("", "0")
         self._overlap = bool(want and self._fused)
@@ -99,7 +105,10 @@ class VerletRun:
 
     # ---- pieces of the loop ---------------------------------------------------------------------------
     def _allreduce_max(self, t: torch.Tensor) -> float:
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if self.native is not None and self.dc.multi:
+            self.native.allreduce(t.data_ptr(), t.numel(), "max", stream=self._stream)
+            return float(t)
+        if dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.dc.multi):
             if dist.get_backend(self.group) == "gloo" and t.is_cuda:
                 c = t.cpu()
                 dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
@@ -111,7 +120,7 @@ class VerletRun:
         """mass-dependent factors of the integrator, expanded once per re-neighbouring (atoms may have migrated) so
         that each update is ONE fused device kernel"""
         n = self.nlocal
-        if self.dc.world == 1 and getattr(self, "_factors_n", -1) == n:
+        if not self.dc.multi and getattr(self, "_factors_n", -1) == n:
             return   # one rank: nobody migrates, the owned atoms keep their order
         self._factors_n = n
         m = self.masses[self.species[:n].long()]
@@ -161,9 +170,11 @@ class VerletRun:
             self.f.zero_()
         self.ani.compute_device(self.ntotal, self.nlocal, None, self.x.data_ptr(), self.npairs, None, None, None, 1,
                                 self.f.data_ptr(), self.ev.data_ptr(), stream=self._stream)
-        if self._fused and self.dc.world == 1:
+        if self._fused and not self.dc.multi:
             self._check(self._md.ani_md_reverse_ghosts(self.f.data_ptr(), self.dc.send_idx.data_ptr(), self.nlocal,
                                                        self.ntotal - self.nlocal, self._stream))
+        elif self._fused and self.native is not None:
+            self.native.reverse(self.f.data_ptr(), self.nlocal, stream=self._stream)
         elif self._fused:
             dc, ns = self.dc, int(self.dc.send_idx.numel())
             if self._recvbuf.shape[0] != ns:
@@ -210,6 +221,9 @@ class VerletRun:
         self.v *= (T / t_now) ** 0.5
 
     def _allreduce_sum(self, t: torch.Tensor) -> float:
+        if self.native is not None and self.dc.multi and t.is_cuda and t.dtype == torch.float64:
+            self.native.allreduce(t.data_ptr(), t.numel(), "sum", stream=self._stream)
+            return float(t)
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             if dist.get_backend(self.group) == "gloo" and t.is_cuda:
                 c = t.cpu()
@@ -252,9 +266,11 @@ class VerletRun:
             self._forces_overlapped()
             self._final_integrate()
             return
-        elif self._fused and self.dc.world == 1:
+        elif self._fused and not self.dc.multi:
             self._check(self._md.ani_md_forward_ghosts(self.x.data_ptr(), self.dc.send_idx.data_ptr(), self.dc.send_shift.data_ptr(),
                                                        self.nlocal, self.ntotal - self.nlocal, self._stream))
+        elif self._fused and self.native is not None:
+            self.native.forward(self.x.data_ptr(), self.nlocal, stream=self._stream)
         elif self._fused:
             # several ranks: one pack kernel, the all-to-all receives straight into the ghost block of x
             dc, ns = self.dc, int(self.dc.send_idx.numel())
@@ -271,9 +287,12 @@ class VerletRun:
     def _pack_and_send_ghosts(self):
         """forward exchange on the current stream: x[nlocal:] <- the owners' positions (+ image shifts)"""
         dc = self.dc
-        if dc.world == 1:
+        if not dc.multi:
             self._check(self._md.ani_md_forward_ghosts(self.x.data_ptr(), dc.send_idx.data_ptr(), dc.send_shift.data_ptr(),
                                                        self.nlocal, self.ntotal - self.nlocal, torch.cuda.current_stream(self.device).cuda_stream))
+            return
+        if self.native is not None:
+            self.native.forward(self.x.data_ptr(), self.nlocal, stream=torch.cuda.current_stream(self.device).cuda_stream)
             return
         ns = int(dc.send_idx.numel())
         if self._sendbuf.shape[0] != ns:
@@ -299,7 +318,9 @@ class VerletRun:
         ev[2].record(s1)                                   # ghost rows of f are final
         with torch.cuda.stream(s2):
             s2.wait_event(ev[2])
-            if dc.world > 1:
+            if dc.multi and self.native is not None:
+                self.native.reverse_send(self.f.data_ptr(), nl, stream=s2.cuda_stream)
+            elif dc.multi:
                 ns = int(dc.send_idx.numel())
                 if self._recvbuf.shape[0] != ns:
                     self._recvbuf = torch.empty((ns, 3), dtype=torch.float64, device=self.device)
@@ -307,7 +328,9 @@ class VerletRun:
             ev[3].record(s2)
         self.ani.step_finish(stream=s1.cuda_stream)
         s1.wait_event(ev[3])
-        if dc.world > 1:
+        if dc.multi and self.native is not None:
+            self.native.reverse_unpack(self.f.data_ptr(), stream=s1.cuda_stream)
+        elif dc.multi:
             self._check(self._md.ani_md_unpack_reverse(self.f.data_ptr(), dc.send_idx.data_ptr(), int(dc.send_idx.numel()),
                                                        self._recvbuf.data_ptr(), s1.cuda_stream))
         else:   # one rank: the owners are here, the ghost rows are added once the owned rows are written
