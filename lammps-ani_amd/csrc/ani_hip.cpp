@@ -506,6 +506,11 @@ int rebuild(ani_handle* h, hipStream_t st) {
 bool fused_eligible(const ani_handle* h) {
   const HostModel& m = h->model;
   if (!h->mlp_fused || h->mlp_arith == MLP_FP32 || m.L != 4) return false;
+  // Several ensemble members: a tile's members run one after the other in its workgroup, so a small system leaves most CUs
+  // idle for eight times as long, and at any size the grouped per-layer launches (which batch the members, as BmmEnsemble
+  // does, models/lammps_ani.py:110) measured faster -- 10 002 atoms x 8: MLP 0.33 against 0.80 ms, CH4/O2 100 008 x 8: 1.55
+  // against 2.54.  mlp_fused = 2 forces the fused kernel (tests, measurements).
+  if (m.M > 1 && h->mlp_fused < 2) return false;
   const int acols = h->ap_run.aev_len;
   if (acols < 16 || (acols & 15) || (h->ap_run.aev_stride & 3)) return false;
   for (int s = 0; s < m.S; s++)
@@ -1499,7 +1504,8 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
     return ANI_OK;
   }
   if (strcmp(name, "mlp_fused") == 0) {
-    h->mlp_fused = value != 0;
+    if (value < 0 || value > 2) { h->err = "mlp_fused must be 0, 1 or 2"; return ANI_ERR_ARG; }
+    h->mlp_fused = value;
     return ANI_OK;
   }
   if (strcmp(name, "mlp_pipeline") == 0) {
@@ -1533,7 +1539,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
 }
 
 // development probe (tools/mlpf_stamps.py): phase cycle counters of a -DABLF_STAMPS build of the fused MLP; 0 otherwise
-int ani_debug_fused_stamps(unsigned long long* out16, int reset) { return fused_read_stamps(out16, reset); }
+int ani_debug_fused_stamps(unsigned long long* out32, int reset) {   // 1: fused MLP stamps, 2: AEV backward stamps, 0: neither built in
+  const int r = fused_read_stamps(out32, reset);
+  return r ? r : aev_read_stamps(out32, reset);
+}
 
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes) {
   if (!h || !d_src || !host_dst) return ANI_ERR_ARG;

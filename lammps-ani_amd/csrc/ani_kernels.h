@@ -123,6 +123,7 @@ void launch_build_stream(const float* src, int ld, int rows_valid, int k_valid, 
                          unsigned short* dst, hipStream_t st);
 hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st);
 // diagnostic builds (-DABLF_STAMPS) only: cycles per phase summed over tiles; returns 0 in the shipped build
+int aev_read_stamps(unsigned long long* out32, int reset);
 int fused_read_stamps(unsigned long long* out16, int reset);
 
 // dst[kb][N][planes][16] 16-bit planes of src[N][ld] (first K columns), kb = ceil(K/16); batch matrices src + i*s_src ->

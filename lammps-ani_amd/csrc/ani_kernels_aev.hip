@@ -82,6 +82,31 @@ __device__ __forceinline__ float fsin_rev(float rev) { return __builtin_amdgcn_s
 #endif
 constexpr float kLog2e = 1.4426950408889634f;
 
+// diagnostic build (-DABLB_STAMPS): wave 0 of every backward workgroup adds the shader-clock cycles it spent in each phase
+// of a centre to g_bwd_stamps (read through ani_debug_fused_stamps); no stamp executes in the shipped kernel
+#ifdef ABLB_STAMPS
+__device__ unsigned long long g_bwd_stamps[32];
+#define BWD_STAMP(k)                                                                          \
+  do {                                                                                        \
+    unsigned long long _t;                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); \
+    stamp_acc[k] += _t - stamp_prev;                                                          \
+    stamp_prev = _t;                                                                          \
+  } while (0)
+#define BWD_STAMP_VM(k)                                                                       \
+  do {                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+    BWD_STAMP(k);                                                                             \
+  } while (0)
+#define BWD_STAMP_PARAMS , unsigned long long& stamp_prev, unsigned long long (&stamp_acc)[8]
+#define BWD_STAMP_ARGS , stamp_prev, stamp_acc
+#else
+#define BWD_STAMP(k) do {} while (0)
+#define BWD_STAMP_VM(k) do {} while (0)
+#define BWD_STAMP_PARAMS
+#define BWD_STAMP_ARGS
+#endif
+
 // unordered pair index t -> (a, b), a < b < n, row-major over the strict upper triangle
 __device__ __forceinline__ void decode_pair(int t, int n, int& a, int& b) {
   // closed form + one branch-free correction step each way; all quantities < 2^14, so 24-bit multiplies are exact
@@ -824,7 +849,7 @@ __device__ __forceinline__ void scatter_neighbours(const AevArgs& a, const float
 template <int NA, int NZ, int NCH, int GR, bool VIR>
 __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
                                                 const Loaded<NCH, true, GR>& pf, int lane, float (&wv)[9],
-                                                const RepTab& rep, float& er) {
+                                                const RepTab& rep, float& er BWD_STAMP_PARAMS) {
   constexpr int NR = 16;
   const int centre = h[0];
 #pragma unroll
@@ -938,9 +963,11 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       wave_sync();   // the staging buffer is reused by the next chunk
     }
   }
+  BWD_STAMP(2);   // radial stage incl. the radial-only scatter
   int nbk;
   const int nrows_stream = build_row_table<NA, NZ>(p, lane, L, nbk);
   wave_sync();
+  BWD_STAMP(3);   // row table
 
   // ---- angular: lane = pair; 4 rows of the stream per step (see build_row_table) ----
   const float cA = -p.EtaA * kLog2e;
@@ -1112,6 +1139,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
    wave_sync();   // the tables are rewritten by the next block of rows; after the last block: gd is complete
   }
 
+  BWD_STAMP(4);   // angular stage
   // ---- the angular neighbours: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d ----
   for (int q = lane; q < nang; q += 64) {
     const float gx = L.gd[3 * q], gy = L.gd[3 * q + 1], gz = L.gd[3 * q + 2];
@@ -1132,6 +1160,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   fz = xor_sum<32>(xor_sum<16>(xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(fz))))));
   if (lane < 3) atomicAdd(&a.fbuf[4 * centre + lane], lane == 0 ? fx : (lane == 1 ? fy : fz));
   wave_sync();  // the LDS slice is reused by this wave's next centre
+  BWD_STAMP(5);   // final scatter
 }
 
 template <int NA, int NZ, int NCH, int GR, bool VIR>
@@ -1141,8 +1170,33 @@ __global__ __launch_bounds__(64 * kWavesB, ANI_BWD_MINW) void aev_backward_fast(
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, true, rowf), cap, true, rowf);
   float wv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this lane's share of the wave's virial
   float er = 0.f;                                                // ... and of its repulsion energy
+#ifdef ABLB_STAMPS
+  unsigned long long stamp_prev, stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+  const int nw = gridDim.x * kWavesB;
+  for (int k = blockIdx.x * kWavesB + wave; k < a.kcount; k += nw) {
+    const int row = a.row_list ? __builtin_amdgcn_readfirstlane(a.row_list[a.k0 + k]) : a.k0 + k;
+    const hdr_t hc = load_header(a, row);
+    BWD_STAMP(0);   // header (waits for whatever this wave still has in flight: the last centre's atomics)
+    if (hc[0] < 0) continue;
+    Loaded<NCH, true, GR> cur;
+    load_lists(p, a, row, hdr_nrad(hc), hdr_nang(hc), lane, cur);
+#ifdef ABLB_STAMPS_VM
+    BWD_STAMP_VM(1);   // list + dE/dAEV row
+#else
+    BWD_STAMP(1);
+#endif
+    backward_centre<NA, NZ, NCH, GR, VIR>(p, a, L, row, hc, cur, lane, wv, rep, er, stamp_prev, stamp_acc);
+    stamp_acc[6] += 1;
+  }
+  if (wave == 0 && lane == 0) {
+    for (int q = 0; q < 6; q++) atomicAdd(&g_bwd_stamps[q], stamp_acc[q]);
+    atomicAdd(&g_bwd_stamps[8], stamp_acc[6]);
+  }
+#else
   ANI_PERSISTENT_LOOP(kWavesB, NCH, true, GR,
                       (backward_centre<NA, NZ, NCH, GR, VIR>(p, a, L, row, hc, cur, lane, wv, rep, er)))
+#endif
   if (rep.on) {
     double se = (double)er;
 #pragma unroll
@@ -1386,6 +1440,20 @@ __global__ __launch_bounds__(64 * kWaves) void aev_backward_generic(AevParams p,
       if (lane == 0) atomicAdd(&a.virial[k], -(double)sv);
     }
   }
+}
+
+int aev_read_stamps(unsigned long long* out32, int reset) {
+#ifdef ABLB_STAMPS
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_bwd_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 2;
+#else
+  (void)out32; (void)reset;
+  return 0;
+#endif
 }
 
 // =====================================================================================================

@@ -16,13 +16,13 @@ for kind, nm, box in (("ani2x", 1, hx.water_box(1500, seed=5)), ("ani1x", 1, hx.
     mf.write_model(path, mf.synthetic_model(kind, nm, seed=2024))
     inp = hx.decompose(box)
     out = {}
-    for fused in (0, 1):
+    for fused in (0, 2):
         ani = ani_hip.ANI(path, 0)
         ani.set_option("mlp_fused", fused)
         out[fused] = ani.compute(inp, ago=0)
         ani.close()
-    df = np.abs(out[1]["force"] - out[0]["force"])
-    de = np.abs(out[1]["eatom"] - out[0]["eatom"])
+    df = np.abs(out[2]["force"] - out[0]["force"])
+    de = np.abs(out[2]["eatom"] - out[0]["eatom"])
     sp = np.asarray(inp.species[: inp.nlocal])
-    print(f"{kind} x{nm}: |dE| {abs(out[1]['energy'] - out[0]['energy']):.3e}  max|dF| {df.max():.3e}  max|de_atom| {de.max():.3e}  "
+    print(f"{kind} x{nm}: |dE| {abs(out[2]['energy'] - out[0]['energy']):.3e}  max|dF| {df.max():.3e}  max|de_atom| {de.max():.3e}  "
           + "  ".join(f"s{s}:{de[sp == s].max():.1e}" for s in np.unique(sp)), flush=True)
