@@ -1,9 +1,17 @@
-// ani_fused_ring.h — bookkeeping of the LDS ring that carries the weight stream of the fused MLP kernel
-// (ani_kernels_mlpf.hip).  Plain integer logic, compiled for the device AND for the host: tests/ring_sim.cpp replays it on
-// the CPU for every compiled shape and checks the two properties the kernel's correctness rests on --
-//   (1) a slab is never read before all of its pieces have been issued (and waited for), and
-//   (2) a refill never writes ring space that a wave may still be reading.
+// ani_fused_ring.h — the LDS slots that carry the weight stream of the fused MLP kernel (ani_kernels_mlpf.hip), and the
+// walk over the stream's slabs.  Plain integer logic, compiled for the device AND for the host: tests/ring_sim.cpp replays it
+// on the CPU for every compiled shape and checks what the kernel's correctness rests on --
+//   (1) the consumer's j-th boundary asks for exactly the slab the issuer's j-th step loaded, in the slot it loaded it to, and
+//   (2) a load never writes a slot whose slab a wave may still be reading.
 // Internal to libani_hip.so.
+//
+// Scheme (version 5; version 4 kept a ring of variable-size slabs with run-time bookkeeping -- fill levels, wrap rules, early
+// and late boundaries, counted waits -- that cost ~150 scalar instructions and a dozen branches per slab on a kernel whose
+// single wave per SIMD issues in order): kSlots = 3 slots of kSlot pieces, slab j lives in slot j mod 3 at a fixed offset.
+// In front of slab j ("boundary j") every wave waits for its own loads in flight (those of slab j, issued one slab earlier),
+// the workgroup barrier follows, and behind it the wave issues its share of slab j + 1 into slot (j + 1) mod 3 -- the slot of
+// slab j - 2.  A boundary may stand in front of the LAST block of slab j - 1 (so that slab j's first fragments are requested
+// beside that block's MFMAs): whoever is past barrier j has finished every block of slab j - 2, which is all the refill needs.
 #pragma once
 
 #if defined(__HIPCC__)
@@ -15,36 +23,24 @@
 
 namespace ani {
 
-#ifndef ANI_FUSED_RING
-#define ANI_FUSED_RING 152
-#endif
-constexpr int kRing = ANI_FUSED_RING;   // pieces (KB) in the LDS ring: with the constants' 4 KB, all of a CU's 160 KB
-ANI_RING_HD int ring_pos(int v) { return (int)((unsigned)v % (unsigned)kRing); }   // virtual position -> ring position
-constexpr int kChunk = 4;               // dE/dAEV tiles walked together through all k-steps (accumulators: 16 registers each)
+constexpr int kSlots = 3;
+constexpr int kSlot = 48;                 // pieces (KB) per slot: the largest slab (two k-steps of an 8-tile first layer, 3 planes)
+constexpr int kRing = kSlots * kSlot;     // pieces of LDS the slots take; with the constants' 4 KB: 148 of a CU's 160 KB
+constexpr int kChunk = 4;                 // dE/dAEV tiles walked together through all k-steps (accumulators: 16 registers each)
 
-// A slab (the pieces a stretch of the kernel consumes between two boundaries) never wraps: a slab that would cross the ring's
-// end starts at its beginning instead, issuer and consumer applying the same rule to the same sequence of slab sizes.
-// Inside a slab every fragment is then at a compile-time offset from one base address (ds_read_b128 ... offset:imm).
 struct Ring {
   const unsigned char* src;   // the tile's weight stream (global), members back to back
   int total;                  // pieces in it
   int qi;                     // next piece of the stream to issue
-  int qg;                     // pieces the consumer has been granted so far (the slabs it has passed a boundary for)
   int iseg, nseg;             // issuer: segment (see segment()) of the next slab to issue; segments per member
   int ileft, isize;           // issuer: slabs left in that segment, pieces per slab of it
-  int vw;                     // issuer: virtual write position (pieces, skipped space included; position = vw mod kRing)
-  int vr;                     // consumer: virtual position of the oldest slab a wave may still be reading
-  int ve;                     // consumer: virtual end of the newest slab it has been granted
-  int own_issued, own_needed; // pieces this wave has issued / that the slabs granted so far needed from this wave
+  int islot, cslot;           // slot the next slab is loaded to / the next boundary reads from
   int ks0, nt0;               // AEV k-steps / dE/dAEV tiles of the problem (the slab sequence depends on them)
 };
 
-// k-steps of the first product per slab: two where three such slabs fit the ring (what the early boundaries need), else one
+// k-steps of the first product per slab: two where such a slab fits a slot, else one
 template <int NT1, int P>
-struct F1Slab { static constexpr int k = (2 * NT1 * P) * 3 <= kRing ? 2 : 1; };
-
-// pieces k = wave, wave + 4, ... < n of a slab: this wave's share
-ANI_RING_HD int own_share(int n, int wave) { return (n - wave + 3) >> 2; }
+struct F1Slab { static constexpr int k = 2 * NT1 * P <= kSlot ? 2 : 1; };
 
 // A member's slabs come in SEGMENTS of equal slabs.  A slab of a forward product (and of dE/dAEV) is TWO k-steps of it (F1:
 // F1Slab::k of them):
@@ -75,55 +71,30 @@ ANI_RING_HD void next_segment(Ring& r) {
 }
 template <int NT1, int NT2, int NT3, int P>
 ANI_RING_HD void ring_reset(Ring& r, const unsigned char* src, int total, int ks0, int nt0) {
-  r.src = src; r.total = total; r.qi = 0; r.qg = 0;
+  r.src = src; r.total = total; r.qi = 0;
   r.ks0 = ks0; r.nt0 = nt0;
   r.nseg = 6 + (nt0 + kChunk - 1) / kChunk;
   r.iseg = r.nseg - 1;
   next_segment<NT1, NT2, NT3, P>(r);   // -> the first segment with slabs in it
-  r.vw = 0; r.vr = 0; r.ve = 0; r.own_issued = 0; r.own_needed = 0;
+  r.islot = 0; r.cslot = 0;
 }
+ANI_RING_HD int next_slot(int s) { return s + 1 == kSlots ? 0 : s + 1; }
 
-// Issuer: if the next slab of the stream fits behind the consumer, take it: first stream piece q0, ring position pos (pieces),
-// size n; the caller starts the loads.
+// Issuer: the next slab of the stream, if any is left: first stream piece q0, size n, slot; the caller starts the loads.
 template <int NT1, int NT2, int NT3, int P>
-ANI_RING_HD bool ring_take(Ring& r, int wave, int& q0, int& pos, int& n) {
+ANI_RING_HD bool ring_take(Ring& r, int& q0, int& n, int& slot) {
   if (r.qi >= r.total) return false;
-  n = r.isize;
-  const int pw = ring_pos(r.vw);
-  const int vws = pw + n > kRing ? r.vw + (kRing - pw) : r.vw;
-  if (vws + n - r.vr > kRing) return false;
-  q0 = r.qi;
-  pos = pw + n > kRing ? 0 : pw;
-  r.own_issued += own_share(n, wave);
+  q0 = r.qi; n = r.isize; slot = r.islot;
   r.qi += n;
-  r.vw = vws + n;
+  r.islot = next_slot(r.islot);
   if (--r.ileft == 0) next_segment<NT1, NT2, NT3, P>(r);
   return true;
 }
-// Consumer, in front of a slab of n pieces.  ring_place: the slab's virtual start (no state change).  ring_issued: whether
-// the refills so far have issued it; if not -- possible only behind early boundaries that protected their predecessor, and
-// only at a LATE boundary, where every older slab is finished -- the caller frees the ring (barrier, ring_before_refill<false>),
-// refills, and then proceeds as usual.  ring_grant, BEFORE the wait and the barrier: how many of this wave's own loads may
-// still be in flight once the slab's pieces have landed.
-ANI_RING_HD int ring_place(const Ring& r, int n) {
-  const int pe = ring_pos(r.ve);
-  return pe + n > kRing ? r.ve + (kRing - pe) : r.ve;
+// Consumer: the slot of the slab the boundary it stands at will read
+ANI_RING_HD int ring_consume(Ring& r) {
+  const int s = r.cslot;
+  r.cslot = next_slot(s);
+  return s;
 }
-ANI_RING_HD bool ring_issued(const Ring& r, int n) { return r.qg + n <= r.qi; }
-ANI_RING_HD int ring_grant(Ring& r, int n, int wave) {
-  r.own_needed += own_share(n, wave);
-  r.qg += n;
-  return r.own_issued - r.own_needed;
-}
-// Whether the boundary of the next slab (n pieces) can be taken EARLY, in front of the last block of the slab being read:
-// only if the refills so far have already issued it (an early boundary protects the slab being read, so its own refill
-// might not find room for it).  Same answer on every wave.  Otherwise the boundary comes after that block.
-ANI_RING_HD bool ring_can_go_early(const Ring& r, int n) { return ring_issued(r, n); }
-// ... AFTER the barrier, around the refill.  EARLY = false: every wave has finished every slab before this one, whose space
-// the refill may take.  EARLY = true: the boundary sits in front of the LAST block of the slab before, which stays protected
-// from this refill; by the next one (behind the next barrier) every wave is past it.
-template <bool EARLY>
-ANI_RING_HD void ring_before_refill(Ring& r, int vs) { if (!EARLY) r.vr = vs; }
-ANI_RING_HD void ring_after_refill(Ring& r, int vs, int n) { r.vr = vs; r.ve = vs + n; }
 
 }  // namespace ani

@@ -167,6 +167,7 @@ struct ani_handle {
   DevBuf<double> nb_xs;
   std::vector<std::vector<double*>> Hbuf64;
   std::vector<std::vector<float*>> Hbuf, Gbuf;  // [S][k] pointers into act: stored activations H_k; raw (unmasked) dE/dh_k
+  bool arena_valid = false;                     // ... laid out for this epoch's row counts (ensure_arena)
   // host staging for the host-pointer entry points
   std::vector<int> h_species32;
   std::vector<int> h_half_num, h_half_j;
@@ -475,8 +476,16 @@ int rebuild(ani_handle* h, hipStream_t st) {
     HIP_TRY(h, h->cl_j.reserve((size_t)std::max(h->nrows, 1) * h->cl_stride));
   }
 
-  // activation arena: per species, H_k (k = 1..L-1; H_{L-1} is overwritten by dE/dz_{L-1}) and the raw gradients
-  // dE/dh_k (k = 1..L-2), whose celu' factor is applied by the product that consumes them
+  h->arena_valid = false;   // the per-layer kernels' activation arena is laid out when they first run in this epoch
+  return ANI_OK;
+}
+
+// activation arena of the per-layer MLP kernels: per species, H_k (k = 1..L-1; H_{L-1} is overwritten by dE/dz_{L-1}) and
+// the raw gradients dE/dh_k (k = 1..L-2), whose celu' factor is applied by the product that consumes them.  The fused
+// kernel keeps all of this in registers: an epoch that only ever runs it never allocates or clears the arena.
+int ensure_arena(ani_handle* h, hipStream_t st) {
+  if (h->arena_valid) return ANI_OK;
+  const HostModel& m = h->model;
   size_t need = 0;
   for (int s = 0; s < m.S; s++) {
     const size_t rows = round_up(h->count[s], kRowTile);
@@ -499,6 +508,7 @@ int rebuild(ani_handle* h, hipStream_t st) {
       off += rows * (size_t)m.M * h->nets[s].w[k];
     }
   }
+  h->arena_valid = true;
   return ANI_OK;
 }
 
@@ -638,6 +648,10 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
 //   H_k   : [rows][M*w[k]]      activations after layer k-1 (member a at column a*w[k]); overwritten by G_k = dE/dz_k
 int compute_mlp(ani_handle* h, hipStream_t st) {
   if (fused_eligible(h)) return compute_mlp_fused(h, st);
+  {
+    const int rca = ensure_arena(h, st);
+    if (rca) return rca;
+  }
   const HostModel& m = h->model;
   const int L = m.L, M = m.M;
   const float alpha = (float)m.alpha, inv_alpha = (float)(1.0 / m.alpha);

@@ -122,79 +122,52 @@ __global__ void build_stream_kernel(const float* __restrict__ src, int ld, int r
   }
 }
 
-// ---- the ring (bookkeeping: ani_fused_ring.h) ---------------------------------------------------------------------
-__device__ __forceinline__ void wait_vmcnt_le(int c) {
-  // "all but the c youngest vector-memory operations of this wave are done".  Rounded down to one of four immediates
-  // (waiting for a few more pieces, issued at least a slab ago, costs nothing; a long chain of cases did); younger loads /
-  // stores of other kinds only make the wait more conservative.
-  if (c >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if (c >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (c >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-// refill: every whole slab that fits behind the consumer
-template <int NT1, int NT2, int NT3, int P>
-__device__ __forceinline__ void ring_issue(Ring& r, unsigned char* ring, int wave, int lane16) {
-  int q0, pos, n;
-  while (ring_take<NT1, NT2, NT3, P>(r, wave, q0, pos, n)) {
+// ---- the weight slots (bookkeeping: ani_fused_ring.h) ----------------------------------------------------------------
+__device__ __forceinline__ void ring_load_piece(const Ring& r, unsigned char* slot_base, int q0, int k, int lane16) {
 #ifndef ABLF_NODMA
-    const unsigned char* g = r.src + (size_t)q0 * 1024 + lane16;
-    unsigned char* l = ring + (pos << 10);
-    for (int k = wave; k < n; k += 4)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)k * 1024),
-                                       (__attribute__((address_space(3))) void*)(l + k * 1024), 16, 0, 0);
+  const unsigned char* g = r.src + (size_t)(q0 + k) * 1024 + lane16;
+  unsigned char* l = slot_base + (k << 10);
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 #endif
+}
+// this wave's share (pieces wave, wave + 4, ...) of the next slab of the stream, into the slot after the last one issued
+template <int NT1, int NT2, int NT3, int P>
+__device__ __forceinline__ void ring_issue_next(Ring& r, unsigned char* ring, int wave, int lane16) {
+  int q0, n, slot;
+  if (ring_take<NT1, NT2, NT3, P>(r, q0, n, slot)) {
+    unsigned char* base = ring + slot * (kSlot << 10);
+    for (int k = wave; k < n; k += 4) ring_load_piece(r, base, q0, k, lane16);
   }
 }
-// In front of a slab of n pieces: returns this lane's read address of the slab's first piece.  EARLY: see ani_fused_ring.h --
-// the call sits in front of the LAST block of the slab before, so that the new slab's first fragments are requested beside
-// that block's MFMAs instead of after them (an LDS round trip with an idle matrix pipe per slab otherwise).
+// In front of a slab: returns this lane's read address of the slab's first piece.  Every wave waits for its own loads (the
+// slab's pieces among them, issued a slab ago), the barrier says that everybody's have landed and that nobody reads the slab
+// two back any more, whose slot the next slab's loads -- issued right behind the barrier -- overwrite.  EARLY marks the calls
+// that stand in front of the LAST block of the slab before (the new slab's first fragments are then requested beside that
+// block's MFMAs instead of after them); the scheme is the same for both.
+__device__ __forceinline__ constexpr bool ring_can_go_early(const Ring&, int) { return true; }
 template <int NT1, int NT2, int NT3, int P, bool EARLY>
 __device__ __forceinline__ const unsigned char* ring_boundary(Ring& r, unsigned char* ring, int n, int wave, int lane16, int* err_flag) {
-  const int vs = ring_place(r, n);
-  if (!EARLY && !ring_issued(r, n)) {
-    // rare (ani_fused_ring.h): the slab is not on its way yet.  Every older slab is finished once all waves are here: free
-    // the ring, request it, then wait for it like for any other
-    asm volatile("s_barrier" ::: "memory");
-    ring_before_refill<false>(r, vs);
-    ring_issue<NT1, NT2, NT3, P>(r, ring, wave, lane16);
-  }
-  int allowed = ring_grant(r, n, wave);
-  if (allowed < 0 || !(r.qg <= r.qi)) {   // cannot happen (tests/ring_sim.cpp); never silently: the step's energy becomes NaN
-    if (lane16 == 0) atomicOr(err_flag, 4);
-    allowed = 0;
-  }
+  (void)n; (void)err_flag;
 #ifndef ABLF_NOWAIT
-  wait_vmcnt_le(allowed);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 #ifndef ABLF_NOBAR
   asm volatile("s_barrier" ::: "memory");
 #else
   asm volatile("" ::: "memory");
 #endif
-  ring_before_refill<EARLY>(r, vs);
-  ring_issue<NT1, NT2, NT3, P>(r, ring, wave, lane16);
-  ring_after_refill(r, vs, n);
-  return ring + (ring_pos(vs) << 10) + lane16;
+  const int s = ring_consume(r);
+  ring_issue_next<NT1, NT2, NT3, P>(r, ring, wave, lane16);
+  return ring + s * (kSlot << 10) + lane16;
 }
-// The boundary of a slab that follows another of the same product: early -- in front of the last block of the slab being
-// read, so that the new slab's first fragments are requested beside that block's MFMAs -- if the slab is already on its way,
-// else late, behind that block.  FUSED_NEXT_SLAB_EARLY goes in front of the last block's MFMAs, FUSED_NEXT_SLAB_LATE behind.
+// The boundary of a slab that follows another of the same product stands in front of the last block of the slab being read
+// (FUSED_NEXT_SLAB_EARLY, ahead of that block's MFMAs); FUSED_NEXT_SLAB_LATE, behind them, is where version 4's ring had to
+// fall back to when the slab was not on its way yet -- with fixed slots it always is.
 #define FUSED_NEXT_SLAB_EARLY(n_, frag_)                                                            \
-  bool late_ = false;                                                                               \
-  if (ring_can_go_early(r, (n_))) {                                                                 \
-    base = ring_boundary<RING_T, true>(r, ring, (n_), wave, lane16, err);                           \
-    read_frag<P>(base, 0, frag_);                                                                   \
-    sched_first_read<P>();                                                                          \
-  } else {                                                                                          \
-    late_ = true;                                                                                   \
-  }
-#define FUSED_NEXT_SLAB_LATE(n_, frag_)                                                             \
-  if (late_) {                                                                                      \
-    base = ring_boundary<RING_T, false>(r, ring, (n_), wave, lane16, err);                          \
-    read_frag<P>(base, 0, frag_);                                                                   \
-    sched_first_read<P>();                                                                          \
-  }
+  base = ring_boundary<RING_T, true>(r, ring, (n_), wave, lane16, err);                             \
+  read_frag<P>(base, 0, frag_);                                                                     \
+  sched_first_read<P>();
+#define FUSED_NEXT_SLAB_LATE(n_, frag_)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int P>
@@ -431,8 +404,8 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
                                            float* cst) {
   using CL = ConstLayout<NT1, NT2, NT3>;
   static_assert(CL::count * 4 <= kConstBytes, "constants do not fit their LDS block");
-  static_assert(2 * 2 * NT2 * P <= kRing && 2 * F1Slab<NT1, P>::k * NT1 * P <= kRing && 2 * 2 * kChunk * P <= kRing,
-                "every slab must fit the ring at least twice");
+  static_assert(2 * NT2 * P <= kSlot && 2 * NT3 * P <= kSlot && F1Slab<NT1, P>::k * NT1 * P <= kSlot && 2 * kChunk * P <= kSlot,
+                "every slab must fit a slot");
   const int c = lane & 31, h = lane >> 5, lane16 = lane * 16;
   int* const err = cx.err;
   const int row = tile * 128 + 32 * wave + c;
@@ -442,7 +415,7 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
   Ring r;
   ring_reset<RING_T>(r, pr.stream, pr.pieces_per_member * cx.M, pr.ks0, pr.nt0);
   FUSED_STAMP_INIT();
-  ring_issue<RING_T>(r, ring, wave, lane16);
+  ring_issue_next<RING_T>(r, ring, wave, lane16);   // slab 0; every later slab is issued at the boundary of the one before
 
   for (int m = 0; m < cx.M; m++) {
     // the member's constants: one piece per wave, then everything issued so far is waited for (the ring's first slabs among

@@ -232,7 +232,8 @@ class VerletRun:
             dist.all_reduce(t, group=self.group)
         return float(t)
 
-    def step(self):
+    def step(self, force_rebuild: bool = False):
+        """force_rebuild: re-neighbour in this step whatever the displacement check would say (measurements)"""
         # fix nve initial_integrate: v += dtf f / m ; x += dt v  (fused: + the displacement maximum of check_distance)
         if self._fused:
             self._check(self._md.ani_md_initial_integrate(self.x.data_ptr(), self.v.data_ptr(), self.f.data_ptr(),
@@ -244,8 +245,8 @@ class VerletRun:
         self.step_no += 1
         self.since_build += 1
         # Neighbor::decide + check_distance (every N steps, rebuild if any atom moved more than skin/2)
-        rebuild = False
-        if self.since_build % self.every == 0:
+        rebuild = bool(force_rebuild)
+        if not rebuild and self.since_build % self.every == 0:
             if self._fused:
                 d2 = self._d2max.clone()    # running maximum since the last look (monotone between rebuilds: same decision)
                 self._d2max.zero_()

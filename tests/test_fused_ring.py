@@ -1,9 +1,10 @@
-"""CPU: the weight ring of the fused MLP kernel, replayed on the host.
+"""CPU: the weight slots of the fused MLP kernel, replayed on the host.
 
 tests/ring_sim.cpp includes lammps-ani_amd/csrc/ani_fused_ring.h -- the very bookkeeping functions the HIP kernel runs --
 and walks the kernel's boundary sequence for every compiled shape, both arithmetics, AEV widths from 16 to 1024 columns
-and one to three ensemble members: no slab may be read before its pieces were issued and waited for (with the kernel's
-rounding of the counted vmcnt wait, per wave), no refill may write ring space that is live or not yet consumed."""
+and one to three ensemble members: every boundary must find the slab it expects (size and slot) already issued, and no
+load may write a slot whose slab a wave may still be reading (a boundary can stand in front of the last block of the slab
+before)."""
 import os
 import subprocess
 
