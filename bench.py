@@ -261,9 +261,17 @@ def main():
             ani.set_option("prune_absent_species", 0)
         # several ranks over RCCL: the exchanges run inside libani_hip.so (include/ani_comm.h: grouped ncclSend / ncclRecv on
         # the compute stream); ANI_BENCH_NATIVE_COMM=0 keeps them on torch.distributed's all_to_all_single for comparison
-        native = None
+        native, native_note = None, None
         if world > 1 and backend == "nccl" and os.environ.get("ANI_BENCH_NATIVE_COMM", "1") not in ("", "0"):
-            native = ani_hip.NativeComm.from_torch(dev_index)
+            try:
+                native = ani_hip.NativeComm.from_torch(dev_index)
+            except Exception as exc:   # still RCCL, through torch.distributed; said so in the JSON line
+                native_note = f"ani_comm unavailable ({exc}); "
+            ok = torch.tensor([1.0 if native is not None else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks or none
+            if float(ok) == 0.0 and native is not None:
+                native.close()
+                native, native_note = None, "ani_comm unavailable on another rank; "
         run = md.VerletRun(ani, inp, system.boxhi - system.boxlo, dev, dt=0.5, langevin=(300.0, 100.0), box_lo=system.boxlo, grid=grid,
                            overlap=True if args.overlap else None, native_comm=native)
         parity = None
@@ -309,7 +317,7 @@ def main():
                 "npairs_rank0": run.npairs, "nlocal_rank0": run.nlocal, "nghost_rank0": run.ntotal - run.nlocal,
                 "temperature_K": 2.0 * ke / (3.0 * natoms_all - 3.0) / md.BOLTZ, "exchange_overlap": bool(run._overlap),
                 "exchange": None if world == 1 else ("ani_comm: grouped ncclSend/ncclRecv inside libani_hip.so" if native is not None else
-                                                     f"torch.distributed all_to_all_single ({backend})"),
+                                                     (native_note or "") + f"torch.distributed all_to_all_single ({backend})"),
                 "energy_finite": bool(np.isfinite(run.potential_energy())), "model_out_scale": MD_OUT_SCALE,
                 "mlp_arith": arith if arith is not None else 1}
         if parity:

@@ -64,6 +64,19 @@ int ani_comm_alltoallv(ani_comm* c, const void* d_send, const int64_t* send_coun
 int ani_comm_set_epoch(ani_comm* c, const int64_t* send_counts, const int64_t* recv_counts, const int64_t* d_send_idx,
                        const double* d_send_shift);
 
+/* The same for callers that hold the maps on the HOST (the LAMMPS adapter): the arrays are copied into device buffers the
+ * communicator owns.  send_shift may be NULL (no image shifts: a caller that only uses the reverse exchange, or whose ghost
+ * positions come from elsewhere; ani_comm_forward then adds nothing); ghost_of may be NULL (ghost block already grouped by
+ * owner), see ani_comm_set_ghost_order. */
+int ani_comm_set_epoch_host(ani_comm* c, const int64_t* send_counts, const int64_t* recv_counts, const int64_t* send_idx,
+                            const double* send_shift, const int64_t* ghost_of);
+
+/* Callers whose ghost block is NOT grouped by owning rank (LAMMPS orders ghosts by the swap that brought them): d_ghost_of[k],
+ * k < nrecv, is the ghost (0-based within the ghost block) that entry k of the rank-grouped message order stands for; the
+ * exchanges then go through a second staging buffer (one gather / scatter kernel more).  NULL = the ghost block is already in
+ * message order (the default).  Kept, not copied; reset by ani_comm_set_epoch. */
+int ani_comm_set_ghost_order(ani_comm* c, const int64_t* d_ghost_of);
+
 /* forward: d_x[nlocal ..) <- owners' current positions + image shift (LAMMPS Comm::forward_comm) */
 int ani_comm_forward(ani_comm* c, double* d_x, int nlocal, void* stream);
 /* reverse: ghost rows d_f[nlocal ..) are added into their owners' rows, on whichever rank those are

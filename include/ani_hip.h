@@ -168,6 +168,16 @@ int ani_build_list(ani_handle* h, int ntotal, int nlocal, const int64_t* species
 /* device pointers of the installed list (tests): numneigh[nlocal], its exclusive scan [nlocal+1], jlist[npairs] */
 int ani_debug_list(ani_handle* h, const int** d_numneigh, const int** d_nbr_off, const int** d_jlist);
 
+/*
+ * Ghost forces over RCCL instead of the caller's host MPI (the reference: comm->reverse_comm(this) after the D2H copy,
+ * src/pair_ani.cpp:197-201,461-484).  With a communicator of include/ani_comm.h attached (maps of the epoch installed by the
+ * caller: ani_comm_set_epoch, and ani_comm_set_ghost_order when the ghost block is in LAMMPS' swap order), the host-pointer
+ * entry points ani_compute_full / ani_compute_half sum every ghost's force into its owner ON THE DEVICE before the forces
+ * leave it: out_force[0 .. 3 nlocal) is then complete, the ghost rows come back as zeros, and the caller skips its reverse
+ * communication.  `comm` is an `ani_comm*` (NULL detaches); not owned by the handle.
+ */
+int ani_attach_comm(ani_handle* h, void* comm);
+
 /* last-step diagnostics for tests / roofline accounting (device pointers valid until the next compute or destroy) */
 typedef struct {
   int nlocal, ntotal, nrows;       /* nrows: species-bucketed AEV rows incl. padding */

@@ -41,6 +41,11 @@ int ani_md_reverse_ghosts(double* f, const int64_t* owner, int nlocal, int nghos
 int ani_md_pack_ghosts(const double* x, const int64_t* owner, const double* shift, int nsend, double* out, void* stream);
 int ani_md_unpack_reverse(double* f, const int64_t* owner, int nsend, const double* in, void* stream);
 
+/* rows of three doubles through an index list:  out[k] = src[idx[k]]  /  dst[idx[k]] = in[k]  (the ghost block of a caller
+ * whose ghosts are not grouped by owner, brought into / out of message order: include/ani_comm.h ani_comm_set_ghost_order) */
+int ani_md_gather_rows(const double* src, const int64_t* idx, int n, double* out, void* stream);
+int ani_md_scatter_rows(double* dst, const int64_t* idx, int n, const double* in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,11 +22,11 @@ EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
            "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times",
            "ani_trace_push", "ani_trace_pop", "ani_trace_mark", "ani_step_begin", "ani_step_ghosts_ready", "ani_step_finish",
-           "ani_debug_fused_stamps"]
+           "ani_debug_fused_stamps", "ani_attach_comm"]
 # include/ani_comm.h: the device-side ghost exchange over RCCL
 COMM_EXPORTS = ["ani_comm_get_unique_id", "ani_comm_create", "ani_comm_destroy", "ani_comm_last_error", "ani_comm_rank",
                 "ani_comm_size", "ani_comm_plan", "ani_comm_exchange_counts", "ani_comm_alltoallv", "ani_comm_set_epoch",
-                "ani_comm_forward", "ani_comm_reverse", "ani_comm_reverse_send", "ani_comm_reverse_unpack",
+                "ani_comm_set_epoch_host", "ani_comm_set_ghost_order", "ani_comm_forward", "ani_comm_reverse", "ani_comm_reverse_send", "ani_comm_reverse_unpack",
                 "ani_comm_allreduce_f64", "ani_comm_set_option"]
 
 
@@ -115,6 +115,11 @@ def lib():
         L.ani_comm_exchange_counts.argtypes = [C.c_void_p] * 4
         L.ani_comm_alltoallv.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
         L.ani_comm_set_epoch.argtypes = [C.c_void_p] * 5
+        L.ani_comm_set_ghost_order.argtypes = [C.c_void_p, C.c_void_p]
+        L.ani_comm_set_epoch_host.argtypes = [C.c_void_p] * 6
+        L.ani_attach_comm.argtypes = [C.c_void_p, C.c_void_p]
+        L.ani_md_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ani_md_scatter_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ani_comm_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ani_comm_reverse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ani_comm_reverse_send.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -254,6 +259,11 @@ class ANI:
     def set_option(self, name: str, value: int):
         self._check(self._lib.ani_set_option(self._h, name.encode(), int(value)))
 
+    def attach_comm(self, comm):
+        """ani_attach_comm: a NativeComm (or None) whose reverse exchange the host-pointer entry points run on the device"""
+        self._comm_keep = comm
+        self._check(self._lib.ani_attach_comm(self._h, comm._h if comm is not None else None))
+
     def phase_timing(self, enable):
         """1/True: fresh accumulation; 0/False: stop recording; 2: resume without clearing."""
         self._check(self._lib.ani_phase_timing(self._h, int(enable)))
@@ -345,6 +355,11 @@ class NativeComm:
         rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
         self._keep = (send_idx, send_shift)
         self._check(self._lib.ani_comm_set_epoch(self._h, sc.ctypes.data, rc.ctypes.data, send_idx.data_ptr(), send_shift.data_ptr()))
+
+    def set_ghost_order(self, ghost_of):
+        """ghost_of (int64 device tensor, or None): entry k of the rank-grouped message order is ghost ghost_of[k]"""
+        self._keep = self._keep + (ghost_of,)
+        self._check(self._lib.ani_comm_set_ghost_order(self._h, ghost_of.data_ptr() if ghost_of is not None else None))
 
     def forward(self, d_x, nlocal: int, stream=None):
         self._check(self._lib.ani_comm_forward(self._h, d_x, nlocal, stream))

@@ -94,7 +94,14 @@ struct ani_comm {
   // staging: positions packed for sending / forces received for unpacking ([nsend][3] doubles), counts for exchange_counts
   double* stage = nullptr;
   size_t stage_cap = 0;
+  const int64_t* d_ghost_of = nullptr;   // message order -> ghost, or NULL (ani_comm_set_ghost_order)
+  double* gstage = nullptr;              // [nrecv][3]: the ghost block in message order
+  size_t gstage_cap = 0;
   int64_t* d_counts = nullptr;
+  // maps handed in as host arrays (ani_comm_set_epoch_host): device copies owned here
+  int64_t *own_idx = nullptr, *own_ghost_of = nullptr;
+  double* own_shift = nullptr;
+  size_t own_idx_cap = 0, own_ghost_cap = 0, own_shift_cap = 0;
 };
 
 #define COMM_HIP(c, expr)                                                                         \
@@ -118,6 +125,17 @@ int reserve_stage(ani_comm* c, size_t doubles) {
   const size_t want = doubles + doubles / 2 + 64;
   COMM_HIP(c, hipMalloc((void**)&c->stage, want * sizeof(double)));
   c->stage_cap = want;
+  return ANI_OK;
+}
+
+template <typename T>
+int grow(ani_comm* c, T** p, size_t* cap, size_t n) {
+  if (n <= *cap && *p) return ANI_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  const size_t want = n + n / 2 + 64;
+  COMM_HIP(c, hipMalloc((void**)p, want * sizeof(T)));
+  *cap = want;
   return ANI_OK;
 }
 
@@ -197,7 +215,11 @@ void ani_comm_destroy(ani_comm* c) {
   (void)hipDeviceSynchronize();
   if (c->comm) (void)rccl()->CommDestroy(c->comm);
   if (c->stage) (void)hipFree(c->stage);
+  if (c->gstage) (void)hipFree(c->gstage);
   if (c->d_counts) (void)hipFree(c->d_counts);
+  if (c->own_idx) (void)hipFree(c->own_idx);
+  if (c->own_ghost_of) (void)hipFree(c->own_ghost_of);
+  if (c->own_shift) (void)hipFree(c->own_shift);
   delete c;
 }
 
@@ -263,7 +285,48 @@ int ani_comm_set_epoch(ani_comm* c, const int64_t* send_counts, const int64_t* r
   memcpy(c->rc.data(), recv_counts, sizeof(int64_t) * c->nranks);
   c->d_send_idx = d_send_idx;
   c->d_send_shift = d_send_shift;
+  c->d_ghost_of = nullptr;
   return reserve_stage(c, (size_t)c->nsend * 3);
+}
+
+int ani_comm_set_epoch_host(ani_comm* c, const int64_t* send_counts, const int64_t* recv_counts, const int64_t* send_idx,
+                            const double* send_shift, const int64_t* ghost_of) {
+  if (!c || !send_counts || !recv_counts) return ANI_ERR_ARG;
+  COMM_HIP(c, hipSetDevice(c->device));
+  int64_t ns = 0, nr = 0;
+  if (ani_comm_plan(c->nranks, send_counts, recv_counts, nullptr, nullptr, &ns, &nr) != ANI_OK) { c->err = "negative count"; return ANI_ERR_ARG; }
+  if (ns > 0 && !send_idx) { c->err = "null send map"; return ANI_ERR_ARG; }
+  int rc = grow(c, &c->own_idx, &c->own_idx_cap, (size_t)ns);
+  if (!rc) rc = grow(c, &c->own_shift, &c->own_shift_cap, (size_t)ns * 3);
+  if (!rc && ghost_of) rc = grow(c, &c->own_ghost_of, &c->own_ghost_cap, (size_t)nr);
+  if (rc) return rc;
+  // plain (synchronous) copies: the caller's arrays may go away when this returns; rebuild steps only
+  if (ns > 0) COMM_HIP(c, hipMemcpy(c->own_idx, send_idx, sizeof(int64_t) * (size_t)ns, hipMemcpyHostToDevice));
+  if (ns > 0) {
+    if (send_shift) COMM_HIP(c, hipMemcpy(c->own_shift, send_shift, sizeof(double) * 3 * (size_t)ns, hipMemcpyHostToDevice));
+    else COMM_HIP(c, hipMemset(c->own_shift, 0, sizeof(double) * 3 * (size_t)ns));
+  }
+  rc = ani_comm_set_epoch(c, send_counts, recv_counts, c->own_idx, c->own_shift);
+  if (rc || !ghost_of) return rc;
+  if (nr > 0) COMM_HIP(c, hipMemcpy(c->own_ghost_of, ghost_of, sizeof(int64_t) * (size_t)nr, hipMemcpyHostToDevice));
+  return ani_comm_set_ghost_order(c, c->own_ghost_of);
+}
+
+int ani_comm_set_ghost_order(ani_comm* c, const int64_t* d_ghost_of) {
+  if (!c) return ANI_ERR_ARG;
+  c->d_ghost_of = d_ghost_of;
+  if (!d_ghost_of) return ANI_OK;
+  COMM_HIP(c, hipSetDevice(c->device));
+  const size_t need = (size_t)c->nrecv * 3;
+  if (need > c->gstage_cap || !c->gstage) {
+    if (c->gstage) (void)hipFree(c->gstage);
+    c->gstage = nullptr;
+    c->gstage_cap = 0;
+    const size_t want = need + need / 2 + 64;
+    COMM_HIP(c, hipMalloc((void**)&c->gstage, want * sizeof(double)));
+    c->gstage_cap = want;
+  }
+  return ANI_OK;
 }
 
 int ani_comm_forward(ani_comm* c, double* d_x, int nlocal, void* stream) {
@@ -273,8 +336,15 @@ int ani_comm_forward(ani_comm* c, double* d_x, int nlocal, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int rc = ani_md_pack_ghosts(d_x, c->d_send_idx, c->d_send_shift, (int)c->nsend, c->stage, st);
   if (rc) { c->err = std::string("pack kernel: ") + hipGetErrorString((hipError_t)rc); return ANI_ERR_DEVICE; }
-  return a2a_bytes(c, reinterpret_cast<const char*>(c->stage), c->sc.data(), c->so.data(), reinterpret_cast<char*>(d_x + 3 * (size_t)nlocal),
-                   c->rc.data(), c->ro.data(), 3 * sizeof(double), st);
+  if (!c->d_ghost_of)
+    return a2a_bytes(c, reinterpret_cast<const char*>(c->stage), c->sc.data(), c->so.data(), reinterpret_cast<char*>(d_x + 3 * (size_t)nlocal),
+                     c->rc.data(), c->ro.data(), 3 * sizeof(double), st);
+  const int rc2 = a2a_bytes(c, reinterpret_cast<const char*>(c->stage), c->sc.data(), c->so.data(), reinterpret_cast<char*>(c->gstage),
+                            c->rc.data(), c->ro.data(), 3 * sizeof(double), st);
+  if (rc2) return rc2;
+  const int rc3 = ani_md_scatter_rows(d_x + 3 * (size_t)nlocal, c->d_ghost_of, (int)c->nrecv, c->gstage, st);
+  if (rc3) { c->err = std::string("scatter kernel: ") + hipGetErrorString((hipError_t)rc3); return ANI_ERR_DEVICE; }
+  return ANI_OK;
 }
 
 int ani_comm_reverse_send(ani_comm* c, const double* d_f, int nlocal, void* stream) {
@@ -282,7 +352,13 @@ int ani_comm_reverse_send(ani_comm* c, const double* d_f, int nlocal, void* stre
   if (c->nsend == 0 && c->nrecv == 0) return ANI_OK;
   COMM_HIP(c, hipSetDevice(c->device));
   // the roles swap: what came in as ghosts goes back to where it came from
-  return a2a_bytes(c, reinterpret_cast<const char*>(d_f + 3 * (size_t)nlocal), c->rc.data(), c->ro.data(), reinterpret_cast<char*>(c->stage),
+  const double* src = d_f + 3 * (size_t)nlocal;
+  if (c->d_ghost_of) {
+    const int rc = ani_md_gather_rows(src, c->d_ghost_of, (int)c->nrecv, c->gstage, stream);
+    if (rc) { c->err = std::string("gather kernel: ") + hipGetErrorString((hipError_t)rc); return ANI_ERR_DEVICE; }
+    src = c->gstage;
+  }
+  return a2a_bytes(c, reinterpret_cast<const char*>(src), c->rc.data(), c->ro.data(), reinterpret_cast<char*>(c->stage),
                    c->sc.data(), c->so.data(), 3 * sizeof(double), (hipStream_t)stream);
 }
 

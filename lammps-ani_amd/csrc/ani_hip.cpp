@@ -10,6 +10,7 @@
 //   AEV backward   gaev -> forces on local+ghost atoms, virial                         (lammps_ani.py:195-216)
 //   finish         fp64 energy sum + self energies, kcal/mol conversion                (ani.cpp:246-262)
 #include "../../include/ani_hip.h"
+#include "../../include/ani_comm.h"
 
 #include <hip/hip_runtime.h>
 #ifndef ANI_NO_ROCTX
@@ -150,6 +151,7 @@ struct ani_handle {
   long long npairs = 0;
   int count[kMaxSpecies] = {0}, row_start[kMaxSpecies] = {0};
 
+  ani_comm* comm = nullptr;   // ani_attach_comm: ghost forces go home on the device (host-pointer entry points)
   int sticky_flags = 0;   // every bit the device error word has ever shown the host (bit 1: LDS capacity, bit 2: MLP wait timeout)
   int max_numneigh = 0;
   DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
@@ -521,6 +523,14 @@ bool fused_eligible(const ani_handle* h) {
   // does, models/lammps_ani.py:110) measured faster -- 10 002 atoms x 8: MLP 0.33 against 0.80 ms, CH4/O2 100 008 x 8: 1.55
   // against 2.54.  mlp_fused = 2 forces the fused kernel (tests, measurements).
   if (m.M > 1 && h->mlp_fused < 2) return false;
+  // Small systems: a fused tile takes ~0.1 ms whatever else happens, so with fewer tiles than CUs the kernel costs that much
+  // however few rows there are, while the chained per-layer launch of small systems scales down with them (MLP, exact
+  // arithmetic: 12 501 atoms 0.098 fused against 0.081 chained; 25 002 atoms 0.102 against 0.121): fused from ~18 000 atoms on.
+  if (h->mlp_fused < 2) {
+    int tiles = 0;
+    for (int s = 0; s < m.S; s++) tiles += round_up(h->count[s], kRowTile) / kRowTile;
+    if (tiles < 140) return false;
+  }
   const int acols = h->ap_run.aev_len;
   if (acols < 16 || (acols & 15) || (h->ap_run.aev_stride & 3)) return false;
   for (int s = 0; s < m.S; s++)
@@ -1058,7 +1068,19 @@ int finish_host(ani_handle* h, int ntotal, int nlocal, int eflag_atom, int vflag
   int flag = 0;
   HIP_TRY(h, hipMemcpyAsync(ev, h->ev.p, sizeof(ev), hipMemcpyDeviceToHost, st));
   HIP_TRY(h, hipMemcpyAsync(&flag, h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
-  if (out_force) HIP_TRY(h, hipMemcpyAsync(out_force, h->f64.p, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyDeviceToHost, st));
+  if (h->comm) {
+    // the pair style's reverse communication, on the device: ghost rows -> their owners' rows (here or on a peer)
+    if (ani_comm_reverse(h->comm, h->f64.p, nlocal, st) != ANI_OK) {
+      h->err = std::string("ani_comm_reverse: ") + ani_comm_last_error(h->comm);
+      return ANI_ERR_DEVICE;
+    }
+    if (out_force) {
+      HIP_TRY(h, hipMemcpyAsync(out_force, h->f64.p, sizeof(double) * 3 * (size_t)nlocal, hipMemcpyDeviceToHost, st));
+      memset(out_force + 3 * (size_t)nlocal, 0, sizeof(double) * 3 * (size_t)(ntotal - nlocal));
+    }
+  } else if (out_force) {
+    HIP_TRY(h, hipMemcpyAsync(out_force, h->f64.p, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyDeviceToHost, st));
+  }
   if (eflag_atom && out_atomic_energies)
     HIP_TRY(h, hipMemcpyAsync(out_atomic_energies, h->eatom.p, sizeof(double) * (size_t)nlocal, hipMemcpyDeviceToHost, st));
   HIP_TRY(h, hipStreamSynchronize(st));
@@ -1472,6 +1494,12 @@ int ani_compute_half(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
   }
   return ani_compute_full(h, ntotal, nlocal, species, coordinates, h->npairs, nullptr, nullptr, nullptr, ago, eflag_atom, vflag,
                           out_energy, out_force, out_atomic_energies, out_virial);
+}
+
+int ani_attach_comm(ani_handle* h, void* comm) {
+  if (!h) return ANI_ERR_ARG;
+  h->comm = static_cast<ani_comm*>(comm);
+  return ANI_OK;
 }
 
 int ani_debug_get(ani_handle* h, ani_debug_view* out) {

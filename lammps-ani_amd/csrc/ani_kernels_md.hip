@@ -100,9 +100,39 @@ __global__ __launch_bounds__(256) void reverse_ghosts_kernel(double* __restrict_
   atomicAdd(&f[3 * owner[g] + k], f[3 * (size_t)nlocal + t]);
 }
 
+// rows[k] = src[idx[k]] (gather) / dst[idx[k]] = rows[k] (scatter): three doubles per row
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double* __restrict__ src, const long long* __restrict__ idx, int n,
+                                                          double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * n) return;
+  const int g = t / 3, k = t - 3 * g;
+  out[t] = src[3 * idx[g] + k];
+}
+__global__ __launch_bounds__(256) void scatter_rows_kernel(double* __restrict__ dst, const long long* __restrict__ idx, int n,
+                                                           const double* __restrict__ in) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * n) return;
+  const int g = t / 3, k = t - 3 * g;
+  dst[3 * idx[g] + k] = in[t];
+}
+
 }  // namespace
 
 extern "C" {
+
+int ani_md_gather_rows(const double* src, const int64_t* idx, int n, double* out, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src,
+                     reinterpret_cast<const long long*>(idx), n, out);
+  return (int)hipGetLastError();
+}
+
+int ani_md_scatter_rows(double* dst, const int64_t* idx, int n, const double* in, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dst,
+                     reinterpret_cast<const long long*>(idx), n, in);
+  return (int)hipGetLastError();
+}
 
 int ani_md_initial_integrate(double* x, double* v, const double* f, const double* dtfm, double dt, int nlocal,
                              const double* x_built, double* d2max, void* stream) {

@@ -10,6 +10,9 @@
        out_force, ghosts are summed to their owners with reverse_comm(this) when newton is off, then f += out_force
        for all ntotal atoms; eng_vdwl, eatom, virial[6] = xx yy zz xy xz yz            (ref :66-233)
      - restart record layout                                                            (ref :408-455)
+   Optional ninth keyword `rcclcomm` (default `mpicomm`): the ghost-force reverse communication (ref :197-201,461-484) runs on
+   the device over RCCL before the forces are copied to the host -- one message per peer instead of LAMMPS' six dependent
+   host swaps; the owner of every ghost is found once per re-neighbouring with comm->forward_comm(this).
    Differences: atom->x is handed over in place (it is one contiguous ntotal*3 block) instead of being copied;
    numneigh is gathered THROUGH ilist (the reference sums numneigh[ii] but walks firstneigh[ilist[ii]], which
    only agrees when ilist is the identity, SURVEY.md section 7 "numneigh indexing wart"); eatom is scattered through
@@ -56,6 +59,7 @@ PairANI::~PairANI() {
     memory->destroy(cutsq);
   }
   if (ani) ani_destroy(ani);
+  if (acomm) ani_comm_destroy(acomm);
 }
 
 void PairANI::allocate() {
@@ -90,9 +94,26 @@ void PairANI::create_model() {
                             use_single ? 1 : 0, &ani);
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(nullptr));
   if (profiling) ani_set_option(ani, "profiling", 1);
+  if (use_rccl) {
+    // one RCCL communicator over the ranks of `world`: rank 0 makes the id, MPI carries it (the only MPI traffic of this path
+    // besides the per-rebuild map exchange)
+    if (acomm) { ani_comm_destroy(acomm); acomm = nullptr; }
+    int me = 0, nprocs = 1;
+    MPI_Comm_rank(world, &me);
+    MPI_Comm_size(world, &nprocs);
+    char id[ANI_COMM_ID_BYTES];
+    memset(id, 0, sizeof(id));
+    if (me == 0 && ani_comm_get_unique_id(id) != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_comm_last_error(nullptr));
+    MPI_Bcast(id, ANI_COMM_ID_BYTES, MPI_BYTE, 0, world);
+    if (ani_comm_create(nprocs, me, id, node_local_rank(), &acomm) != ANI_OK)
+      error->one(FLERR, std::string("Pair ani: ") + ani_comm_last_error(nullptr));
+    ani_attach_comm(ani, acomm);
+    comm_forward = 2;
+  }
 }
 
-/* pair_style ani cutoff model_file device [num_models] [cuaev|pyaev] [full|half] [single|double] [hostlist|devlist] */
+/* pair_style ani cutoff model_file device [num_models] [cuaev|pyaev] [full|half] [single|double] [hostlist|devlist]
+   [mpicomm|rcclcomm] */
 void PairANI::settings(int narg, char** arg) {
   if (narg < 3) error->all(FLERR, "Illegal pair_style command");
   cutoff = utils::numeric(FLERR, arg[0], false, lmp);
@@ -122,6 +143,11 @@ void PairANI::settings(int narg, char** arg) {
     if (strcmp(arg[7], "devlist") == 0) use_devlist = true;
     else if (strcmp(arg[7], "hostlist") != 0) error->all(FLERR, "neighbor list source should be hostlist or devlist");
     if (use_devlist && !use_fullnbr) error->all(FLERR, "devlist builds a full neighbor list: use it with 'full'");
+  }
+  use_rccl = false;
+  if (narg > 8) {
+    if (strcmp(arg[8], "rcclcomm") == 0) use_rccl = true;
+    else if (strcmp(arg[8], "mpicomm") != 0) error->all(FLERR, "ghost-force communication should be mpicomm or rcclcomm");
   }
   create_model();
 }
@@ -232,6 +258,8 @@ void PairANI::compute(int eflag, int vflag) {
     }
   }
 
+  if (use_rccl && ago == 0) build_rccl_maps(nlocal, atom->nghost);
+
   out_force.resize((size_t)ntotal * 3);
   if (eflag_atom) out_eatom.resize(use_fullnbr ? inum : nlocal);
   double out_energy = 0.0;
@@ -258,7 +286,7 @@ void PairANI::compute(int eflag, int vflag) {
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(ani));
 
   // ghost forces go home from out_force (f's ghost entries are not cleared between steps when newton is off)
-  if (!force->newton) {
+  if (!force->newton && !use_rccl) {   // rcclcomm: the library has summed them on the device (ani_attach_comm)
     ani_trace_push("reverse_comm");   // src/pair_ani.cpp:198-200
     comm->reverse_comm(this);
     ani_trace_pop();
@@ -335,4 +363,57 @@ void PairANI::unpack_reverse_comm(int n, int* list, double* buf) {
     out_force[3 * j + 1] += buf[m++];
     out_force[3 * j + 2] += buf[m++];
   }
+}
+
+/* ---- rcclcomm: who owns each ghost, and what each peer holds of ours -------------------------------------------------
+   forward_comm(this) carries {owning rank, index there} from every owned atom to all of its ghost images (through ghosts of
+   ghosts as LAMMPS' swaps do); the ghosts are then grouped by owner, the counts cross with MPI_Alltoall, the index lists with
+   MPI_Alltoallv, and the library keeps the maps on the device until the next re-neighbouring. */
+int PairANI::pack_forward_comm(int n, int* list, double* buf, int, int*) {
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    buf[m++] = owner_info[2 * (size_t)list[i]];
+    buf[m++] = owner_info[2 * (size_t)list[i] + 1];
+  }
+  return m;
+}
+
+void PairANI::unpack_forward_comm(int n, int first, double* buf) {
+  int m = 0;
+  for (int i = first; i < first + n; i++) {
+    owner_info[2 * (size_t)i] = buf[m++];
+    owner_info[2 * (size_t)i + 1] = buf[m++];
+  }
+}
+
+void PairANI::build_rccl_maps(int nlocal, int nghost) {
+  int me = 0, nprocs = 1;
+  MPI_Comm_rank(world, &me);
+  MPI_Comm_size(world, &nprocs);
+  owner_info.assign(2 * (size_t)(nlocal + nghost), -1.0);
+  for (int i = 0; i < nlocal; i++) { owner_info[2 * (size_t)i] = me; owner_info[2 * (size_t)i + 1] = i; }
+  comm->forward_comm(this);
+  std::vector<int> recv_n(nprocs, 0), send_n(nprocs, 0), rdisp(nprocs + 1, 0), sdisp(nprocs + 1, 0);
+  for (int g = 0; g < nghost; g++) {
+    const int p = (int)owner_info[2 * (size_t)(nlocal + g)];
+    if (p < 0 || p >= nprocs) error->one(FLERR, "Pair ani rcclcomm: a ghost atom has no owner (forward_comm did not reach it)");
+    recv_n[p]++;
+  }
+  for (int p = 0; p < nprocs; p++) rdisp[p + 1] = rdisp[p] + recv_n[p];
+  std::vector<int64_t> ghost_of(nghost);
+  std::vector<int> lidx(nghost), fill(rdisp.begin(), rdisp.end() - 1);
+  for (int g = 0; g < nghost; g++) {   // stable: ghosts of one owner keep their order
+    const int p = (int)owner_info[2 * (size_t)(nlocal + g)];
+    ghost_of[fill[p]] = g;
+    lidx[fill[p]++] = (int)owner_info[2 * (size_t)(nlocal + g) + 1];
+  }
+  MPI_Alltoall(recv_n.data(), 1, MPI_INT, send_n.data(), 1, MPI_INT, world);
+  for (int p = 0; p < nprocs; p++) sdisp[p + 1] = sdisp[p] + send_n[p];
+  std::vector<int> mine(sdisp[nprocs]);
+  MPI_Alltoallv(lidx.data(), recv_n.data(), rdisp.data(), MPI_INT, mine.data(), send_n.data(), sdisp.data(), MPI_INT, world);
+  std::vector<int64_t> send_idx(mine.begin(), mine.end()), sc(send_n.begin(), send_n.end()), rc(recv_n.begin(), recv_n.end());
+  for (int64_t v : send_idx)
+    if (v < 0 || v >= nlocal) error->one(FLERR, "Pair ani rcclcomm: a peer asked for an atom this rank does not own");
+  if (ani_comm_set_epoch_host(acomm, sc.data(), rc.data(), send_idx.data(), nullptr, ghost_of.data()) != ANI_OK)
+    error->one(FLERR, std::string("Pair ani: ") + ani_comm_last_error(acomm));
 }

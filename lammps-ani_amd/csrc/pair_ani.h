@@ -24,6 +24,7 @@ PairStyle(ani,PairANI);
 #include <string>
 #include <vector>
 
+#include "ani_comm.h"
 #include "ani_hip.h"
 #include "pair.h"
 
@@ -43,6 +44,8 @@ class PairANI : public Pair {
   void read_restart(FILE*) override;
   int pack_reverse_comm(int, int, double*) override;
   void unpack_reverse_comm(int, int*, double*) override;
+  int pack_forward_comm(int, int*, double*, int, int*) override;
+  void unpack_forward_comm(int, int, double*) override;
 
  protected:
   double cutoff = 0.0;
@@ -51,6 +54,12 @@ class PairANI : public Pair {
   int use_num_models = -1;
   bool use_cuaev = true, use_fullnbr = true, use_single = true;
   bool use_devlist = false;  // not part of the restart record (kept byte-compatible with the reference): restarts come back as hostlist
+  // `rcclcomm`: ghost forces go home on the device over RCCL (include/ani_comm.h) instead of through comm->reverse_comm(this)
+  // on the host; not part of the restart record
+  bool use_rccl = false;
+  ani_comm* acomm = nullptr;
+  std::vector<double> owner_info;   // [ntotal][2] {owning rank, index on that rank}, filled for ghosts by forward_comm(this)
+  void build_rccl_maps(int nlocal, int nghost);
   bool profiling = false;  // LAMMPS_ANI_PROFILING: passed to the library as option "profiling" (stream sync before returning)
 
   // list epoch (rebuilt when neighbor->ago == 0), grown 1.5x like the reference (src/pair_ani.cpp:119-127)

@@ -20,6 +20,17 @@ typedef int MPI_Info;
 inline int MPI_Comm_rank(MPI_Comm, int* r) { *r = 0; return 0; }
 inline int MPI_Comm_split_type(MPI_Comm, int, int, MPI_Info, MPI_Comm* c) { *c = 1; return 0; }
 inline int MPI_Comm_free(MPI_Comm*) { return 0; }
+// one rank: the collectives the adapter's rcclcomm bootstrap uses are copies
+typedef int MPI_Datatype;
+#define MPI_BYTE 1
+#define MPI_INT 4
+inline int MPI_Comm_size(MPI_Comm, int* n) { *n = 1; return 0; }
+inline int MPI_Bcast(void*, int, MPI_Datatype, int, MPI_Comm) { return 0; }
+inline int MPI_Alltoall(const void* s, int n, MPI_Datatype t, void* r, int, MPI_Datatype, MPI_Comm) { memcpy(r, s, (size_t)n * t); return 0; }
+inline int MPI_Alltoallv(const void* s, const int* sn, const int* sd, MPI_Datatype t, void* r, const int*, const int* rd, MPI_Datatype, MPI_Comm) {
+  memcpy((char*)r + (size_t)rd[0] * t, (const char*)s + (size_t)sd[0] * t, (size_t)sn[0] * t);
+  return 0;
+}
 
 #define FLERR __FILE__, __LINE__
 #define NEIGHMASK 0x1FFFFFFF
@@ -96,6 +107,7 @@ class Comm {
   int nlocal = 0;
   double cutghost[3] = {0, 0, 0};   // ghost cutoff per dimension (comm.h)
   void reverse_comm(Pair* p);
+  void forward_comm(Pair* p);   // per-atom data of the pair style from every owner to its ghosts
 };
 
 class Domain {   // the members of domain.h the adapter reads
@@ -146,7 +158,7 @@ class Pair : protected Pointers {
   double eng_vdwl = 0, eng_coul = 0;
   double virial[6] = {0, 0, 0, 0, 0, 0};
   double* eatom = nullptr;
-  int comm_reverse = 0, comm_reverse_off = 0, single_enable = 1, writedata = 0, restartinfo = 1;
+  int comm_forward = 0, comm_reverse = 0, comm_reverse_off = 0, single_enable = 1, writedata = 0, restartinfo = 1;
   NeighList* list = nullptr;
 
   virtual void compute(int, int) = 0;
@@ -159,6 +171,8 @@ class Pair : protected Pointers {
   virtual void read_restart(FILE*) {}
   virtual int pack_reverse_comm(int, int, double*) { return 0; }
   virtual void unpack_reverse_comm(int, int*, double*) {}
+  virtual int pack_forward_comm(int, int*, double*, int, int*) { return 0; }
+  virtual void unpack_forward_comm(int, int, double*) {}
 
   void ev_init(int eflag, int vflag) {
     eflag_either = eflag;
@@ -188,6 +202,14 @@ inline void Comm::reverse_comm(Pair* p) {
   std::vector<double> buf(3 * (size_t)ng);
   p->pack_reverse_comm(ng, nlocal, buf.data());
   p->unpack_reverse_comm(ng, owner.data(), buf.data());
+}
+
+inline void Comm::forward_comm(Pair* p) {
+  const int ng = (int)owner.size();
+  if (!ng) return;
+  std::vector<double> buf((size_t)(p->comm_forward > 0 ? p->comm_forward : 1) * ng);
+  p->pack_forward_comm(ng, owner.data(), buf.data(), 0, nullptr);
+  p->unpack_forward_comm(ng, nlocal, buf.data());
 }
 
 namespace utils {

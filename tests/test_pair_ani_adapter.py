@@ -166,3 +166,36 @@ def test_adapter_devlist_matches_hostlist(mock, model_cache, aev):
     assert rc == 1 and "full" in err
     rc, err = _style(mock, h, ["5.1", p, "hip", "-1", aev, "full", "single", "gpulist"])
     assert rc == 1 and "hostlist or devlist" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbr", ["full", "half"])
+def test_adapter_rcclcomm_matches_mpicomm(mock, model_cache, nbr):
+    """`... single hostlist rcclcomm`: the ghost-force reverse communication runs on the device through include/ani_comm.h
+    (owners found with comm->forward_comm(this), maps handed to the library per re-neighbouring, forces summed before the
+    D2H copy) instead of comm->reverse_comm(this) on the host (src/pair_ani.cpp:197-201,461-484).  One rank: the ghosts are
+    the box's periodic images, their owner is this rank; forces of the owned atoms must equal the host path's and the
+    fixtures, and the ghost rows must come back untouched (nothing left to reverse-communicate)."""
+    g = load_golden("water30_pbc_ani2x_m8")
+    inp = golden_input(g, half=(nbr == "half"))
+    p = golden_model_path(g, model_cache)
+    out = {}
+    for mode in ("mpicomm", "rcclcomm"):
+        h = mock.mock_create(b"real", 0)
+        rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", nbr, "single", "hostlist", mode])
+        assert rc == 0, err
+        for ago in (0, 1, 0):
+            out[mode] = _run(mock, h, inp, ago)
+        mock.mock_destroy(h)
+    (fm, em, vm, _), (fr, er, vr, _) = out["mpicomm"], out["rcclcomm"]
+    np.testing.assert_allclose(fr[: inp.nlocal], fm[: inp.nlocal], rtol=0, atol=1e-3)
+    assert np.all(fr[inp.nlocal:] == 0.0)
+    assert abs(er - em) < 1e-6
+    np.testing.assert_allclose(vr, vm, rtol=0, atol=1e-2)
+    ref_f = g["strict_force"]
+    folded = ref_f[: inp.nlocal].copy()
+    np.add.at(folded, inp.owner_lidx, ref_f[inp.nlocal:])
+    np.testing.assert_allclose(fr[: inp.nlocal], folded, rtol=0, atol=2.3e-3)
+    h = mock.mock_create(b"real", 0)
+    rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", nbr, "single", "hostlist", "ucxcomm"])
+    assert rc == 1 and "mpicomm or rcclcomm" in err

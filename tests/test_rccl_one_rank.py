@@ -99,6 +99,27 @@ def _worker(rank, port, model_path, out_dir):
     res["fwd_err"] = (x - x_ref).abs().max().item()
     res["rev_err"] = (f[:nl] - f_ref[:nl]).abs().max().item()
     res["allreduce"] = t.cpu().numpy()
+    # ghosts in another order than the messages (LAMMPS' swap order): host maps, ani_comm_set_epoch_host + ghost order
+    import ctypes as C
+    perm = torch.randperm(ng, generator=g)                     # message slot k stands for ghost perm[k]
+    idx_h = idx.cpu().numpy().astype(np.int64)
+    shift_h = np.ascontiguousarray(shift.cpu().numpy())
+    cnt = np.array([ng], dtype=np.int64)
+    perm_h = perm.numpy().astype(np.int64)
+    lib = ani_hip.lib()
+    assert lib.ani_comm_set_epoch_host(nat._h, cnt.ctypes.data, cnt.ctypes.data, idx_h.ctypes.data, shift_h.ctypes.data,
+                                       perm_h.ctypes.data) == 0
+    x2 = torch.randn((nl + ng, 3), generator=g, dtype=torch.float64).to(dev)
+    f2 = torch.randn((nl + ng, 3), generator=g, dtype=torch.float64).to(dev)
+    x2_ref = x2.clone()
+    x2_ref[nl + perm.to(dev)] = x2[:nl][idx] + shift
+    f2_ref = f2.clone()
+    f2_ref[:nl].index_add_(0, idx, f2[nl + perm.to(dev)])
+    nat.forward(x2.data_ptr(), nl, stream=st)
+    nat.reverse(f2.data_ptr(), nl, stream=st)
+    torch.cuda.synchronize()
+    res["fwd_err_perm"] = (x2 - x2_ref).abs().max().item()
+    res["rev_err_perm"] = (f2[:nl] - f2_ref[:nl]).abs().max().item()
     nat.close()
     np.savez(os.path.join(out_dir, "out.npz"), **res)
     dist.destroy_process_group()
@@ -124,3 +145,5 @@ def test_one_rank_drives_the_multi_rank_paths_over_rccl(tmp_path):
     assert float(d["fwd_err"]) == 0.0
     assert float(d["rev_err"]) < 1e-12
     assert d["allreduce"].tolist() == [1.5, -2.0, 7.25]
+    assert float(d["fwd_err_perm"]) == 0.0
+    assert float(d["rev_err_perm"]) < 1e-12
