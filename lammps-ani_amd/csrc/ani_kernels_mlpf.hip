@@ -276,6 +276,9 @@ __device__ __forceinline__ void sched_block() {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x002, ANI_FUSED_VALU_PER_MFMA, 0);
   }
+#ifdef ANI_FUSED_BLOCK_FENCE   // experiment: nothing moves across the end of a block
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
 }
 
