@@ -35,6 +35,8 @@ struct Ring {
   int iseg, nseg;             // issuer: segment (see segment()) of the next slab to issue; segments per member
   int ileft, isize;           // issuer: slabs left in that segment, pieces per slab of it
   int islot, cslot;           // slot the next slab is loaded to / the next boundary reads from
+  int pq0, pslot, pn, pk;     // the slab whose loads are being issued a piece per block: first stream piece, slot, size, this
+                              // wave's next piece of it (pk >= pn: nothing pending)
   int ks0, nt0;               // AEV k-steps / dE/dAEV tiles of the problem (the slab sequence depends on them)
 };
 
@@ -77,6 +79,7 @@ ANI_RING_HD void ring_reset(Ring& r, const unsigned char* src, int total, int ks
   r.iseg = r.nseg - 1;
   next_segment<NT1, NT2, NT3, P>(r);   // -> the first segment with slabs in it
   r.islot = 0; r.cslot = 0;
+  r.pq0 = 0; r.pslot = 0; r.pn = 0; r.pk = 0;
 }
 ANI_RING_HD int next_slot(int s) { return s + 1 == kSlots ? 0 : s + 1; }
 

@@ -130,13 +130,46 @@ __device__ __forceinline__ void ring_load_piece(const Ring& r, unsigned char* sl
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 #endif
 }
-// this wave's share (pieces wave, wave + 4, ...) of the next slab of the stream, into the slot after the last one issued
+// this wave's share (pieces wave, wave + 4, ...) of the next slab of the stream, into the slot after the last one issued.
+// An LDS-DMA instruction holds the wave's issue for 60 cycles and more: a slab's nine to twelve in one burst behind the
+// barrier leave the matrix pipe idle for as long as twenty MFMAs (measured: 0.331 ms per step at 100 002 atoms).  So the
+// loads go one per block (ring_drip, called in front of a block's MFMAs: 0.308 ms; with a burst of the first two or four
+// pieces 0.311 / 0.324), and whatever is left at the next boundary is issued there (ring_flush), before its wait.
+// -DANI_FUSED_NODRIP restores the burst.
+#ifndef ANI_FUSED_NODRIP
+#define ANI_FUSED_DRIP
+#endif
+#ifndef ANI_FUSED_DRIP_HEAD
+#define ANI_FUSED_DRIP_HEAD 0
+#endif
+__device__ __forceinline__ void ring_drip(Ring& r, unsigned char* ring, int lane16) {
+#ifdef ANI_FUSED_DRIP
+  if (r.pk < r.pn) {
+    ring_load_piece(r, ring + r.pslot * (kSlot << 10), r.pq0, r.pk, lane16);
+    r.pk += 4;
+  }
+#endif
+}
+__device__ __forceinline__ void ring_flush(Ring& r, unsigned char* ring, int lane16) {
+#ifdef ANI_FUSED_DRIP
+  while (r.pk < r.pn) {
+    ring_load_piece(r, ring + r.pslot * (kSlot << 10), r.pq0, r.pk, lane16);
+    r.pk += 4;
+  }
+#endif
+}
 template <int NT1, int NT2, int NT3, int P>
 __device__ __forceinline__ void ring_issue_next(Ring& r, unsigned char* ring, int wave, int lane16) {
   int q0, n, slot;
   if (ring_take<NT1, NT2, NT3, P>(r, q0, n, slot)) {
     unsigned char* base = ring + slot * (kSlot << 10);
+#ifdef ANI_FUSED_DRIP
+    int k = wave;
+    for (int i = 0; i < ANI_FUSED_DRIP_HEAD && k < n; i++, k += 4) ring_load_piece(r, base, q0, k, lane16);
+    r.pq0 = q0; r.pslot = slot; r.pn = n; r.pk = k;
+#else
     for (int k = wave; k < n; k += 4) ring_load_piece(r, base, q0, k, lane16);
+#endif
   }
 }
 // In front of a slab: returns this lane's read address of the slab's first piece.  Every wave waits for its own loads (the
@@ -148,6 +181,7 @@ __device__ __forceinline__ constexpr bool ring_can_go_early(const Ring&, int) { 
 template <int NT1, int NT2, int NT3, int P, bool EARLY>
 __device__ __forceinline__ const unsigned char* ring_boundary(Ring& r, unsigned char* ring, int n, int wave, int lane16, int* err_flag) {
   (void)n; (void)err_flag;
+  ring_flush(r, ring, lane16);
 #ifndef ABLF_NOWAIT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -310,11 +344,11 @@ __device__ __forceinline__ void product_reg(Ring& r, unsigned char* ring, const 
       }
       if (next_slab) {
         FUSED_NEXT_SLAB_EARLY(SB * P, fa[(idx + 1) & 1])
-        mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[nt]);
+        ring_drip(r, ring, lane16); mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[nt]);
         sched_block<P, false>();
         FUSED_NEXT_SLAB_LATE(SB * P, fa[(idx + 1) & 1])
       } else {
-        mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[nt]);
+        ring_drip(r, ring, lane16); mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[nt]);
         if (j + 1 < SB) sched_block<P, true>(); else sched_block<P, false>();
       }
       if (nt == NT - 1 && ks + 1 < KS) pin<P>(bq[(ks + 1) & 1]);
@@ -353,10 +387,10 @@ __device__ __forceinline__ void product_inplace(Ring& r, unsigned char* ring, co
       }
       if (next_slab) {
         FUSED_NEXT_SLAB_EARLY(KS * P, fa[(idx + 1) & 1])
-        mma_frag<P>(fa[idx & 1], bf[ks], acc[nt & 1]);
+        ring_drip(r, ring, lane16); mma_frag<P>(fa[idx & 1], bf[ks], acc[nt & 1]);
         FUSED_NEXT_SLAB_LATE(KS * P, fa[(idx + 1) & 1])
       } else {
-        mma_frag<P>(fa[idx & 1], bf[ks], acc[nt & 1]);
+        ring_drip(r, ring, lane16); mma_frag<P>(fa[idx & 1], bf[ks], acc[nt & 1]);
       }
       if (ks == 1 && nt > 0) {
 #pragma unroll
@@ -473,7 +507,7 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
           for (int nt = 0; nt < NT1; nt++) {
             if (nt + 1 < NT1 || two) read_frag<P>(base, nt + 1, fa[(nt + 1) & 1]);
             cvt(nt, v1a, v1b, b1);
-            mma_frag<P>(fa[nt & 1], b0, X1[nt]);
+            ring_drip(r, ring, lane16); mma_frag<P>(fa[nt & 1], b0, X1[nt]);
             sched_block<P, true>();
           }
           pin<P>(b1);
@@ -488,11 +522,11 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
               if (nt + 1 == NT1 && kp + 1 < nslab) {
                 const int nn = min(2, ks0 - 2 * (kp + 1)) * NT1 * P;
                 FUSED_NEXT_SLAB_EARLY(nn, fa[0])      // (j + 1) & 1 == 0: block 0 of the next slab
-                mma_frag<P>(fa[j & 1], b1, X1[nt]);
+                ring_drip(r, ring, lane16); mma_frag<P>(fa[j & 1], b1, X1[nt]);
                 sched_block<P, false>();
                 FUSED_NEXT_SLAB_LATE(nn, fa[0])
               } else {
-                mma_frag<P>(fa[j & 1], b1, X1[nt]);
+                ring_drip(r, ring, lane16); mma_frag<P>(fa[j & 1], b1, X1[nt]);
                 if (nt + 1 < NT1) sched_block<P, true>(); else sched_block<P, false>();
               }
             }
@@ -513,11 +547,11 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
             cvt(nt, v1a, v1b, b0n);       // k-step ks + 1
             if (nt + 1 == NT1 && ks + 1 < ks0) {
               FUSED_NEXT_SLAB_EARLY(NT1 * P, fa[0])
-              mma_frag<P>(fa[nt & 1], b0, X1[nt]);
+              ring_drip(r, ring, lane16); mma_frag<P>(fa[nt & 1], b0, X1[nt]);
               sched_block<P, false>();
               FUSED_NEXT_SLAB_LATE(NT1 * P, fa[0])
             } else {
-              mma_frag<P>(fa[nt & 1], b0, X1[nt]);
+              ring_drip(r, ring, lane16); mma_frag<P>(fa[nt & 1], b0, X1[nt]);
               if (nt + 1 < NT1) sched_block<P, true>(); else sched_block<P, false>();
             }
           }
@@ -595,11 +629,11 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
             if (ks + 1 < 2 * NT1) split_pair_of<P>(G1, ks + 1, t, cx.a_bwd, bq[(ks + 1) & 1]);
             if (j + 1 == SB && kp + 1 < NT1) {
               FUSED_NEXT_SLAB_EARLY(SB * P, fa[(idx + 1) & 1])
-              mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[t]);
+              ring_drip(r, ring, lane16); mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[t]);
               sched_block<P, false>();
               FUSED_NEXT_SLAB_LATE(SB * P, fa[(idx + 1) & 1])
             } else {
-              mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[t]);
+              ring_drip(r, ring, lane16); mma_frag<P>(fa[idx & 1], bq[ks & 1], acc[t]);
               if (j + 1 < SB) sched_block<P, true>(); else sched_block<P, false>();
             }
             if (t == kChunk - 1 && ks + 1 < 2 * NT1) pin<P>(bq[(ks + 1) & 1]);
