@@ -206,8 +206,10 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *   "mlp_fused" (default 1): networks of three hidden layers (every ANI-1x / ANI-2x member) run as ONE launch in which a
  *       workgroup takes a 128-row tile through all six products of every member with the activations in registers
  *       (ani_kernels_mlpf.hip); HBM sees the AEV rows and the dE/dAEV rows only.  0 = the per-layer kernels below.  Needs a
- *       split arithmetic ("mlp_arith" 1 or 2).  With several ensemble members the per-layer kernels (members batched per
- *       launch) are faster and are used; 2 = the fused kernel for any member count (tests).  Takes effect at the next call.
+ *       split arithmetic ("mlp_arith" 1 or 2).  With several ensemble members a work item is (tile, member), each
+ *       member writing its own dE/dAEV rows, summed afterwards.  One member and fewer than ~18 000 atoms: the chained per-layer
+ *       launch is faster and is used.  2 = the fused kernel whatever the size, 3 = the same with a tile's members one after
+ *       the other in its workgroup (tests, measurements).  Takes effect at the next call.
  *   "mlp_arith" (default 1): how the MLP evaluates its fp32 products; fp32 accumulation in every case, takes effect at
  *       the next call.  1, the exact split, is what the reference's "fp32 with TF32 off" means on this chip; 2 is the
  *       counterpart of its opt-in LAMMPS_ANI_ALLOW_TF32 (src/ani_csrc/ani.cpp:41-43), also selected by that variable.

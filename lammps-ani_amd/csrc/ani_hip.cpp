@@ -121,6 +121,7 @@ struct ani_handle {
                        // workgroup with the activations in registers (ani_kernels_mlpf.hip); 0 = the per-layer kernels
   int fused_mask[2] = {-2, -2};   // active_mask the fused streams of each arithmetic were built for
   DevBuf<int> fused_counter;
+  DevBuf<float> gaev_parts;   // fused MLP with (tile, member) work items: every member's own dE/dAEV rows
   int mlp_chain = 1;   // ani_set_option("mlp_chain"): 1 = one chained launch for the MLP of small systems, 2 = at any size, 0 = never
   ChainPlan chain_plan;
   bool profiling = false;  // ani_set_option("profiling"): every entry point synchronises its stream before returning
@@ -518,15 +519,10 @@ int ensure_arena(ani_handle* h, hipStream_t st) {
 bool fused_eligible(const ani_handle* h) {
   const HostModel& m = h->model;
   if (!h->mlp_fused || h->mlp_arith == MLP_FP32 || m.L != 4) return false;
-  // Several ensemble members: a tile's members run one after the other in its workgroup, so a small system leaves most CUs
-  // idle for eight times as long, and at any size the grouped per-layer launches (which batch the members, as BmmEnsemble
-  // does, models/lammps_ani.py:110) measured faster -- 10 002 atoms x 8: MLP 0.33 against 0.80 ms, CH4/O2 100 008 x 8: 1.55
-  // against 2.54.  mlp_fused = 2 forces the fused kernel (tests, measurements).
-  if (m.M > 1 && h->mlp_fused < 2) return false;
   // Small systems: a fused tile takes ~0.1 ms whatever else happens, so with fewer tiles than CUs the kernel costs that much
   // however few rows there are, while the chained per-layer launch of small systems scales down with them (MLP, exact
   // arithmetic: 12 501 atoms 0.098 fused against 0.081 chained; 25 002 atoms 0.102 against 0.121): fused from ~18 000 atoms on.
-  if (h->mlp_fused < 2) {
+  if (h->mlp_fused < 2 && m.M == 1) {   // (several members: the fused kernel's (tile, member) work items win at every size measured)
     int tiles = 0;
     for (int s = 0; s < m.S; s++) tiles += round_up(h->count[s], kRowTile) / kRowTile;
     if (tiles < 140) return false;
@@ -633,6 +629,7 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
       FusedProb& p = G.p[np];
       p.aev = h->aev.p + (size_t)h->row_start[s] * ka;
       p.gaev = h->gaev.p + (size_t)h->row_start[s] * ka;
+      p.gaev_row0 = h->row_start[s];
       p.e_rows = h->e_rows.p + h->row_start[s];
       p.centre_of_row = h->centre_of_row.p + h->row_start[s];
       p.stream = n.fu[pi].stream; p.consts = n.fu[pi].consts;
@@ -647,7 +644,21 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
     }
   G.tile_start[np] = total;
   G.nprob = np;
+  // Several members: a work item is (tile, member) -- M times the parallelism, and an even finish -- each member writing its
+  // own dE/dAEV rows, summed by one small kernel (MLP ms, exact arithmetic, 8 members, against the grouped per-layer launches:
+  // 10 002 water atoms 0.250 / 0.453, 25 002: 0.543 / 0.818, 50 001: 0.995 / 1.578, CH4/O2 100 008 (ANI-1x): 1.65 / 2.03; a
+  // tile's members one after the other in its workgroup: 0.608 at 10 002 atoms).  The copies cost M times the dE/dAEV array:
+  // beyond 8 GB the members run in sequence instead.
+  const size_t parts_bytes = (size_t)std::max(h->nrows, 1) * ka * sizeof(float) * m.M;
+  G.member_items = (m.M > 1 && parts_bytes <= ((size_t)8 << 30) && h->mlp_fused != 3) ? 1 : 0;
+  if (G.member_items) {
+    const size_t per = (size_t)std::max(h->nrows, 1) * ka;
+    HIP_TRY(h, h->gaev_parts.reserve(per * m.M));
+    G.gaev_parts = h->gaev_parts.p;
+    G.part_stride = (long long)per;
+  }
   HIP_TRY(h, launch_mlp_fused(G, arith, st));
+  if (G.member_items) launch_sum_parts(h->gaev_parts.p, G.part_stride, m.M, h->gaev.p, (long long)h->nrows * ka, st);
   return ANI_OK;
 }
 
@@ -1177,7 +1188,7 @@ void ani_destroy(ani_handle* h) {
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();
   free_fused(h, 0); free_fused(h, 1);
-  h->fused_counter.release();
+  h->fused_counter.release(); h->gaev_parts.release();
   free_chain_plan(h->chain_plan);
   for (auto& e : h->evt_pool) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1546,7 +1557,7 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
     return ANI_OK;
   }
   if (strcmp(name, "mlp_fused") == 0) {
-    if (value < 0 || value > 2) { h->err = "mlp_fused must be 0, 1 or 2"; return ANI_ERR_ARG; }
+    if (value < 0 || value > 3) { h->err = "mlp_fused must be 0, 1, 2 or 3"; return ANI_ERR_ARG; }
     h->mlp_fused = value;
     return ANI_OK;
   }

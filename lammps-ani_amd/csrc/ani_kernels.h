@@ -94,6 +94,7 @@ constexpr int kMaxProblems = 16;   // species buckets per launch
 struct FusedProb {
   const float* aev;             // [rows][aev_stride] rows of the bucket
   float* gaev;                  // [rows][aev_stride] dE/dAEV out
+  long long gaev_row0;          // first row of the problem in the step's dE/dAEV array (FusedArgs::member_items)
   float* e_rows;                // member m's row energies at e_rows + m * sE
   const int* centre_of_row;     // >= 0 for real rows
   const unsigned char* stream;
@@ -108,6 +109,11 @@ struct FusedArgs {
   FusedProb p[kMaxProblems];
   int tile_start[kMaxProblems + 1];   // prefix of tiles per problem, costliest problems first
   int nprob, M;
+  int member_items;                   // 1: a work item is (tile, member) and member m writes its dE/dAEV rows to
+                                      //    gaev_parts + m * part_stride (summed afterwards: launch_sum_parts); 0: a work item is a
+                                      //    tile whose members run one after the other, accumulating in gaev
+  float* gaev_parts;
+  long long part_stride;              // floats per member in gaev_parts (= rows of the whole step x aev_stride)
   float alpha, inv_alpha, scale;      // CELU; scale = 1 / M
   int* counter;                       // device word the workgroups draw tiles from (zeroed by the launcher)
   int* err_flag;                      // device error word: bit 4 = the weight ring's schedule broke (cannot happen: tests/ring_sim.cpp)
@@ -122,6 +128,9 @@ long long fused_pieces_per_member(int shape, int acols, int P);
 void launch_build_stream(const float* src, int ld, int rows_valid, int k_valid, int NT, int KS, int chunk, int P, float scale,
                          unsigned short* dst, hipStream_t st);
 hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st);
+int fused_num_cus();
+// dst[i] = sum over m < M of parts[m * part_stride + i], i < n (n a multiple of 4, 16-byte aligned pointers)
+void launch_sum_parts(const float* parts, long long part_stride, int M, float* dst, long long n, hipStream_t st);
 // diagnostic builds (-DABLF_STAMPS) only: cycles per phase summed over tiles; returns 0 in the shipped build
 int aev_read_stamps(unsigned long long* out32, int reset);
 int fused_read_stamps(unsigned long long* out16, int reset);

@@ -431,6 +431,9 @@ __device__ __forceinline__ void epilogue_celu(f32x16 (&X)[NT], const float* b, i
 struct TileCtx {
   float alpha, inv_alpha, scale, a_fwd, a_bwd;
   int M;
+  int m0, m1;          // members this work item runs
+  float* parts;        // member_items: per-member dE/dAEV buffers, else null
+  long long part_stride;
   int* err;   // device error word (bit 4: the ring schedule broke)
 };
 
@@ -448,13 +451,16 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
   const int row = tile * 128 + 32 * wave + c;
   const float valid = pr.centre_of_row[row] >= 0 ? cx.scale : 0.f;
   const float* __restrict__ arow = pr.aev + (size_t)row * pr.aev_stride + 4 * h;
-  float* __restrict__ grow = pr.gaev + (size_t)row * pr.aev_stride + 4 * h;
+  // dE/dAEV rows: the step's array (members accumulate one after the other), or this member's own copy of it (work items
+  // per member: pr.gaev_row0 is the problem's first row in the step's array, the same offset applies in every copy)
+  float* __restrict__ grow = (cx.parts ? cx.parts + (size_t)cx.m0 * cx.part_stride + (size_t)pr.gaev_row0 * pr.aev_stride : pr.gaev) +
+                             (size_t)row * pr.aev_stride + 4 * h;
   Ring r;
-  ring_reset<RING_T>(r, pr.stream, pr.pieces_per_member * cx.M, pr.ks0, pr.nt0);
+  ring_reset<RING_T>(r, pr.stream + (size_t)cx.m0 * pr.pieces_per_member * 1024, pr.pieces_per_member * (cx.m1 - cx.m0), pr.ks0, pr.nt0);
   FUSED_STAMP_INIT();
   ring_issue_next<RING_T>(r, ring, wave, lane16);   // slab 0; every later slab is issued at the boundary of the one before
 
-  for (int m = 0; m < cx.M; m++) {
+  for (int m = cx.m0; m < cx.m1; m++) {
     // the member's constants: one piece per wave, then everything issued so far is waited for (the ring's first slabs among
     // it: they are needed next anyway)
     {
@@ -669,7 +675,7 @@ __device__ __forceinline__ void fused_tile(const TileCtx& cx, const FusedProb& p
             if (f0 + 4 * h < pr.acols) {
               float4 o = make_float4(acc[t][4 * q] * inv_b1, acc[t][4 * q + 1] * inv_b1, acc[t][4 * q + 2] * inv_b1, acc[t][4 * q + 3] * inv_b1);
               float4* dst = reinterpret_cast<float4*>(grow + f0);
-              if (m > 0) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+              if (m > cx.m0) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
               *dst = o;
             }
           }
@@ -691,13 +697,20 @@ __global__ __launch_bounds__(256, 1) void mlp_fused(FusedArgs G) {
   TileCtx cx;
   cx.alpha = G.alpha; cx.inv_alpha = G.inv_alpha; cx.scale = G.scale; cx.M = G.M; cx.err = G.err_flag;
   cx.a_fwd = P == 2 ? 16.f : 1.f; cx.a_bwd = P == 2 ? 4096.f : 1.f;
-  const int total = G.tile_start[G.nprob];
+  cx.m0 = 0; cx.m1 = G.M; cx.parts = nullptr; cx.part_stride = 0;
+  const int per_tile = G.member_items ? G.M : 1;   // work items per tile (members side by side: they share the AEV rows in L2)
+  const int total = G.tile_start[G.nprob] * per_tile;
   for (;;) {
     __syncthreads();   // every wave is done with the tile before (ring, constants, s_tile)
     if (threadIdx.x == 0) s_tile = atomicAdd(G.counter, 1);
     __syncthreads();
-    const int t = __builtin_amdgcn_readfirstlane(s_tile);
-    if (t >= total) break;
+    const int item = __builtin_amdgcn_readfirstlane(s_tile);
+    if (item >= total) break;
+    const int t = item / per_tile;
+    if (G.member_items) {
+      cx.m0 = item - t * per_tile; cx.m1 = cx.m0 + 1;
+      cx.parts = G.gaev_parts; cx.part_stride = G.part_stride;
+    }
     int pi = 0;
     while (pi + 1 < G.nprob && t >= G.tile_start[pi + 1]) pi++;
     const FusedProb& pr = G.p[pi];
@@ -743,6 +756,24 @@ int fused_read_stamps(unsigned long long* out16, int reset) {
 #endif
 }
 
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float4* __restrict__ parts, long long stride4, int M, float4* __restrict__ dst,
+                                                        long long n4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = parts[i];
+  for (int m = 1; m < M; m++) {
+    const float4 b = parts[(long long)m * stride4 + i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  dst[i] = a;
+}
+void launch_sum_parts(const float* parts, long long part_stride, int M, float* dst, long long n, hipStream_t st) {
+  const long long n4 = n / 4;
+  if (n4 <= 0) return;
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(parts),
+                     part_stride / 4, M, reinterpret_cast<float4*>(dst), n4);
+}
+
 void launch_build_stream(const float* src, int ld, int rows_valid, int k_valid, int NT, int KS, int chunk, int P, float scale,
                          unsigned short* dst, hipStream_t st) {
   const long long total = (long long)NT * KS * 512;
@@ -751,13 +782,18 @@ void launch_build_stream(const float* src, int ld, int rows_valid, int k_valid, 
                      chunk, P, scale, dst);
 }
 
-hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st) {
+int fused_num_cus() {
   static int ncu = [] {
     int dev = 0, v = 256;
     if (hipGetDevice(&dev) == hipSuccess) note_launch_error(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
     return v > 0 ? v : 256;
   }();
-  const int total = G.tile_start[G.nprob];
+  return ncu;
+}
+
+hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st) {
+  const int ncu = fused_num_cus();
+  const int total = G.tile_start[G.nprob] * (G.member_items ? G.M : 1);
   if (total <= 0) return hipSuccess;
   hipError_t e = hipMemsetAsync(G.counter, 0, sizeof(int), st);
   if (e != hipSuccess) return e;

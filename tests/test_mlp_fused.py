@@ -25,14 +25,19 @@ def _box(name):
     return hx.random_box(700, 7, 22.0, seed=9)
 
 
+@pytest.mark.parametrize("mode", [2, 3], ids=["member-items", "members-in-sequence"])
 @pytest.mark.parametrize("arith", [1, 2], ids=["bf16x3", "f16x2"])
 @pytest.mark.parametrize("kind,nm,box", CASES, ids=[f"{k}-m{m}-{b}" for k, m, b in CASES])
-def test_fused_mlp_equals_per_layer_kernels(kind, nm, box, arith, tmp_path):
+def test_fused_mlp_equals_per_layer_kernels(kind, nm, box, arith, mode, tmp_path):
+    """mode: mlp_fused 2 = small systems with several members run (tile, member) work items, each member writing its own
+    dE/dAEV rows (summed by a second kernel); 3 = a tile's members one after the other in its workgroup."""
+    if nm == 1 and mode == 3:
+        pytest.skip("one member: both modes are the same kernel path")
     path = str(tmp_path / "m.anim")
     mf.write_model(path, mf.synthetic_model(kind, nm, seed=2024))
     inp = hx.decompose(_box(box))
     out = {}
-    for fused in (0, 2):
+    for fused in (0, mode):
         ani = ani_hip.ANI(path, 0)
         ani.set_option("mlp_fused", fused)
         ani.set_option("mlp_arith", arith)
@@ -41,23 +46,29 @@ def test_fused_mlp_equals_per_layer_kernels(kind, nm, box, arith, tmp_path):
             again = ani.compute(inp, ago=1)
             assert np.array_equal(again["force"], out[fused]["force"]) or np.abs(again["force"] - out[fused]["force"]).max() < 1e-4
         ani.close()
-    assert np.isfinite(out[2]["energy"])
-    assert abs(out[2]["energy"] - out[0]["energy"]) < 2e-3
-    assert np.abs(out[2]["force"] - out[0]["force"]).max() < 2e-4
-    assert np.abs(out[2]["eatom"] - out[0]["eatom"]).max() < 1e-4
-    assert np.abs(out[2]["virial"] - out[0]["virial"]).max() < 2e-2
+    assert np.isfinite(out[mode]["energy"])
+    assert abs(out[mode]["energy"] - out[0]["energy"]) < 2e-3
+    assert np.abs(out[mode]["force"] - out[0]["force"]).max() < 2e-4
+    assert np.abs(out[mode]["eatom"] - out[0]["eatom"]).max() < 1e-4
+    assert np.abs(out[mode]["virial"] - out[0]["virial"]).max() < 2e-2
 
 
-def test_several_members_take_the_per_layer_kernels_by_default(tmp_path):
-    """mlp_fused = 1 (default) with 8 members must give what mlp_fused = 0 gives bit for bit: the same kernels ran."""
-    path = str(tmp_path / "m8.anim")
-    mf.write_model(path, mf.synthetic_model("ani2x", 8, seed=7))
+def test_default_choice_of_mlp_kernels(tmp_path):
+    """mlp_fused = 1 (default): eight members run the fused kernel's (tile, member) work items (= mlp_fused 2, bit for bit:
+    the same kernels in the same order); one member on a small box runs the chained per-layer launch (= mlp_fused 0)."""
+    p8, p1 = str(tmp_path / "m8.anim"), str(tmp_path / "m1.anim")
+    mf.write_model(p8, mf.synthetic_model("ani2x", 8, seed=7))
+    mf.write_model(p1, mf.synthetic_model("ani2x", 1, seed=7))
     inp = hx.decompose(hx.water_box(600, seed=2))
-    res = []
-    for fused in (0, 1):
+
+    def run(path, fused):
         ani = ani_hip.ANI(path, 0)
         ani.set_option("mlp_fused", fused)
-        res.append(ani.compute(inp, ago=0))
+        out = ani.compute(inp, ago=0)
         ani.close()
-    assert res[0]["energy"] == res[1]["energy"]
-    assert np.array_equal(res[0]["eatom"], res[1]["eatom"])
+        return out
+
+    a, b = run(p8, 1), run(p8, 2)
+    assert a["energy"] == b["energy"] and np.array_equal(a["eatom"], b["eatom"])
+    a, b = run(p1, 1), run(p1, 0)
+    assert a["energy"] == b["energy"] and np.array_equal(a["eatom"], b["eatom"])
