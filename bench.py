@@ -446,18 +446,27 @@ def main():
             # transcendentals, DPP and integer instructions hold a slot longer, so the pipes are busier than this says
             return n * 2.4 / (1024 * 2.4e9 * t_ms * 1e-3) if n and t_ms > 0 else None
 
+        def valu4(prefix, t_ms):
+            # the same count at the four cycles a wave64 fp32 instruction is seen to hold a SIMD's vector unit in these
+            # kernels (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.2 cycles; phase stamps + ISA counts), at the
+            # nominal 2.4 GHz -- the chip clocks lower under load, so the units are busier still
+            n = counter(prefix, "SQ_INSTS_VALU")
+            return n * 4.0 / (1024 * 2.4e9 * t_ms * 1e-3) if n and t_ms > 0 else None
+
         bwd_roof = dict(bound="hbm", achieved=bb / (t_bwd * 1e-3) / 1e9 if t_bwd > 0 else None, peak=PEAK_HBM_GBS, unit="GB/s",
                         traffic=hbm_traffic("ani::aev_backward"), kernel="aev_backward_fast", ms_per_launch=t_bwd, bytes_per_launch=bb,
-                        valu_frac=valu("ani::aev_backward", t_bwd),
-                        note="bound by vector-ALU issue, not by HBM (DESIGN.md 3.1): ~2000 VALU wave-instructions per centre; "
-                             "valu_frac = SQ_INSTS_VALU x 2.4 cycles / (1024 SIMDs x time) is the share of plain-FMA issue slots used",
+                        valu_frac=valu("ani::aev_backward", t_bwd), valu_frac_4cyc=valu4("ani::aev_backward", t_bwd),
+                        note="bound by vector-ALU issue, not by HBM (DESIGN.md 3.1): 1822 VALU wave-instructions per centre, 61 % of "
+                             "a centre's cycles in the angular stage's 4 x 330 vector instructions; valu_frac = SQ_INSTS_VALU x 2.4 "
+                             "cycles / (1024 SIMDs x time x 2.4 GHz), valu_frac_4cyc the same at the 4 cycles per instruction these "
+                             "kernels are seen to issue at",
                         counters=pmc_note)
         bwd_roof["frac"] = bwd_roof["achieved"] / PEAK_HBM_GBS if bwd_roof["achieved"] else None
         t_f = t_fwd + t_cmp
         fwd_roof = dict(bound="hbm", achieved=bf / (t_f * 1e-3) / 1e9 if t_f > 0 else None, peak=PEAK_HBM_GBS, unit="GB/s",
                         traffic=(hbm_traffic("ani::aev_forward") or 0) + (hbm_traffic("ani::nbr_compact") or 0) if pmc else None,
                         kernel="nbr_compact_kernel + aev_forward_fast", ms_per_launch=t_f, ms_compact=t_cmp, ms_forward=t_fwd,
-                        bytes_per_launch=bf, valu_frac=valu("ani::aev_forward", t_fwd))
+                        bytes_per_launch=bf, valu_frac=valu("ani::aev_forward", t_fwd), valu_frac_4cyc=valu4("ani::aev_forward", t_fwd))
         fwd_roof["frac"] = fwd_roof["achieved"] / PEAK_HBM_GBS if fwd_roof["achieved"] else None
         # The MLP against the three things that can bound it.  The library default evaluates an fp32 product EXACTLY as six
         # bf16 MFMA products (mlp_arith 1), so the matrix pipe it runs on is the 16-bit one and executes 6x the algorithmic flops.
