@@ -445,7 +445,7 @@ int rebuild(ani_handle* h, hipStream_t st) {
     if (rcs) return rcs;
   }
   // neighbour segments grouped by species: what lets the AEV kernels accumulate without atomics
-  launch_sort_jlist(h->species.p, h->nbr_off.p, h->numneigh.p, h->jraw.p, h->jlist.p, nlocal, m.S, st);
+  launch_sort_jlist(h->species.p, h->nbr_off.p, h->numneigh.p, h->jraw.p, h->jlist.p, nlocal, m.S, info[2 * kMaxSpecies + 3], st);
 
   const size_t stride = h->ap_run.aev_stride;
   if (!h->use_single) {

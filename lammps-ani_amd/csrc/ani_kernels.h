@@ -213,7 +213,7 @@ bool launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
 bool aev_fast_path(const AevParams& p, int max_numneigh);
 // rebuild time: stable sort of every centre's neighbour segment by neighbour species (jin -> jout)
 void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_numneigh, const int* d_jin, int* d_jout,
-                       int nlocal, int S, hipStream_t st);
+                       int nlocal, int S, int present_mask, hipStream_t st);
 
 // device-side neighbour list (ani_kernels_nbr.hip): cells of edge >= cutneigh over [lo, hi)
 struct NbrGrid {
