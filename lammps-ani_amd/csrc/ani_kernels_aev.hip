@@ -548,6 +548,60 @@ __device__ __forceinline__ void stream_pair(const FastLds& L, int nbk, int t, in
   ib = e0.w + b;
 }
 
+// Backward, dense pair stream: the forward pass's bucket table without the padding of bucket starts (nothing here needs a
+// bucket to start on a lane multiple).  entry: {tstart, a1, n1, a2, n2, outoff, tri, npairs}; returns the stream length.
+template <int NA, int NZ>
+__device__ __forceinline__ int build_pair_table(const AevParams& p, int lane, FastLds& L, int& nbk) {
+  const int nb_all = p.S * (p.S + 1) / 2;
+  int s1 = 0, s2 = 0, np = 0, n1 = 0, n2 = 0;
+  if (lane < nb_all) {
+    int rem = lane;
+    while (rem >= p.S - s1) { rem -= p.S - s1; s1++; }
+    s2 = s1 + rem;
+    n1 = L.astart[s1 + 1] - L.astart[s1];
+    n2 = L.astart[s2 + 1] - L.astart[s2];
+    np = (s1 == s2) ? n1 * (n1 - 1) / 2 : n1 * n2;
+  }
+  const int incl = wave_incl_scan(np);
+  const unsigned long long m = __ballot(np > 0);
+  if (np > 0) {
+    int* e = L.tb + 8 * lanes_below(m);
+    e[0] = incl - np; e[1] = L.astart[s1]; e[2] = n1; e[3] = L.astart[s2]; e[4] = n2;
+    e[5] = p.radial_len + lane * (NA * NZ); e[6] = (s1 == s2) ? 1 : 0; e[7] = np;
+  }
+  nbk = __popcll(m);
+  return __builtin_amdgcn_readlane(incl, 63);
+}
+// lane -> its pair of the dense stream: row neighbour ia, column neighbour ib, the bucket's dE/dAEV block, and pos = the
+// pair's position in its run (the consecutive pairs that share ia).  Lanes past the end: valid = false, pos = 0 (they look
+// like the start of a run of their own and carry a harmless geometry of two distinct neighbours).
+__device__ __forceinline__ void stream_pair_run(const FastLds& L, int nbk, int t, int& ia, int& ib, int& outoff, int& pos, bool& valid) {
+  int e = 0;
+  for (int k = 1; k < nbk; k++)
+    if (t >= L.tb[8 * k]) e = k;
+  const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);       // tstart, a1, n1, a2
+  const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);   // n2, outoff, tri, npairs
+  const int u = t - e0.x;
+  valid = nbk > 0 && u < e1.w;
+  outoff = e1.y;
+  int a = 0, b = 0;
+  pos = 0;
+  if (valid) {
+    if (e1.z) {
+      decode_pair(u, e0.z, a, b);
+      pos = b - a - 1;
+    } else {
+      a = (int)(((float)u + 0.5f) * frcp((float)e1.x));
+      b = u - a * e1.x;
+      pos = b;
+    }
+  } else if (e1.z) {
+    b = 1;  // distinct neighbours keep the padded geometry finite
+  }
+  ia = e0.y + a;
+  ib = e0.w + b;
+}
+
 #ifdef ABL_NO_TWRITE
 #define TILE_ADD(p, v) asm volatile("" ::"v"(p), "v"(v))
 #else
@@ -965,6 +1019,105 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     }
   }
   BWD_STAMP(2);   // radial stage incl. the radial-only scatter
+#ifndef ANI_BWD_ROWS
+  // ---- angular, dense pair stream (round 3): the pairs of all non-empty species-pair buckets form ONE stream, bucket after
+  // bucket, pair after pair in row-major order of (row neighbour a, column neighbour b) -- the forward pass's enumeration
+  // without its padding.  A step takes 64 consecutive pairs whatever buckets they belong to: a water centre's 153 pairs are 3
+  // steps (the row layout below, with one 16-lane row per row neighbour, needed 4: 60 % of its lanes held a pair; removing
+  // one step from every centre took 13 % off the kernel).  The pairs that share their ROW neighbour are consecutive lanes (a
+  // run); its gradient is summed over the run by a segmented scan inside each 16-lane DPP row -- level d adds the value d
+  // lanes down if that lane belongs to the same run -- and the last lane of the run in its DPP row adds the partial sum to the
+  // neighbour's LDS accumulator.  The COLUMN neighbour's gradient is one LDS add per lane, as before.
+  int nbk;
+  const int total_pairs = build_pair_table<NA, NZ>(p, lane, L, nbk);
+  wave_sync();
+  BWD_STAMP(3);   // pair table
+  const float cA = -p.EtaA * kLog2e;
+#ifdef ABL_NO_ANG
+  for (int base = 0; base < 0; base += 64) {
+#else
+  for (int base = 0; base < total_pairs; base += 64) {
+#endif
+    int ia, ib, outoff, pos;
+    bool valid;
+    stream_pair_run(L, nbk, base + lane, ia, ib, outoff, pos, valid);
+    const float4 A = L.ad[ia], B = L.ad[ib];
+    const float inv_ra = frcp(A.w), inv_rb = frcp(B.w);
+    const float inv_rr = inv_ra * inv_rb;
+    const float cosv = (A.x * B.x + A.y * B.y + A.z * B.z) * inv_rr;
+    const float c = 0.95f * cosv;
+    const float s2 = fmaxf(1.f - c * c, 1e-12f);
+    const float inv_s = frsq(s2);
+    const float sn = s2 * inv_s;
+    const float fa = L.afc[ia], fb = L.afc[ib];
+    const float dfa = -0.5f * p.pi_over_Rca * fsin_rev(A.w * revA);
+    const float dfb = -0.5f * p.pi_over_Rca * fsin_rev(B.w * revA);
+    const float rho = 0.5f * (A.w + B.w);
+    float f1[NZ], df1[NZ];
+#pragma unroll
+    for (int z = 0; z < NZ; z++) {
+      const float bz = fmaxf(0.5f * (1.f + c * p.cosZ[z] + sn * p.sinZ[z]), 0.f);
+      const float pm1 = fexp2((p.Zeta - 1.f) * flog2(bz));
+      f1[z] = pm1 * bz;
+      df1[z] = p.Zeta * pm1 * 0.5f * (sn * p.cosZ[z] - c * p.sinZ[z]) * inv_s;
+    }
+    const float4* gg4 = reinterpret_cast<const float4*>(L.row + outoff);  // outoff is a multiple of NA*NZ
+    float Aq = 0.f, Bq = 0.f, Cq = 0.f;
+    float drA = rho - p.ShfA0;
+#pragma unroll
+    for (int sa = 0; sa < NA; sa++) {
+#ifdef ANI_GG_SPLIT
+      // keep the compiler from loading all NA x NZ dE/dAEV values of the bucket before the first is used (32 registers):
+      // the second half of the shifts is fetched after the first half has been contracted
+      if (sa == NA / 2) asm volatile("" ::: "memory");
+#endif
+      const float dr = drA;
+      drA -= p.dShfA;   // equidistant shifts
+      const float f2 = fexp2(cA * dr * dr);
+      const float df2 = -2.f * p.EtaA * dr * f2;
+      float g1 = 0.f, gd1 = 0.f;
+#pragma unroll
+      for (int z4 = 0; z4 < NZ / 4; z4++) {
+        const float4 gv = gg4[sa * (NZ / 4) + z4];
+        g1 = fmaf(gv.x, f1[4 * z4], g1); gd1 = fmaf(gv.x, df1[4 * z4], gd1);
+        g1 = fmaf(gv.y, f1[4 * z4 + 1], g1); gd1 = fmaf(gv.y, df1[4 * z4 + 1], gd1);
+        g1 = fmaf(gv.z, f1[4 * z4 + 2], g1); gd1 = fmaf(gv.z, df1[4 * z4 + 2], gd1);
+        g1 = fmaf(gv.w, f1[4 * z4 + 3], g1); gd1 = fmaf(gv.w, df1[4 * z4 + 3], gd1);
+      }
+      Aq = fmaf(f2, gd1, Aq);
+      Cq = fmaf(f2, g1, Cq);
+      Bq = fmaf(df2, g1, Bq);
+    }
+    // gradient of this pair w.r.t. the two neighbour displacements; zero for masked lanes
+    const float P = valid ? fa * fb : 0.f;
+    Aq *= 2.f * P * 0.95f;
+    Bq *= P;       // 2 * P * 0.5
+    Cq *= valid ? 2.f : 0.f;
+    const float cc = Aq * inv_rr;
+    const float ta = (Bq + Cq * dfa * fb) * inv_ra - Aq * cosv * inv_ra * inv_ra;
+    const float tb = (Bq + Cq * fa * dfb) * inv_rb - Aq * cosv * inv_rb * inv_rb;
+    const float va[3] = {cc * B.x + ta * A.x, cc * B.y + ta * A.y, cc * B.z + ta * A.z};  // d/d(neighbour ia)
+    const float vb[3] = {cc * A.x + tb * B.x, cc * A.y + tb * B.y, cc * A.z + tb * B.z};  // d/d(neighbour ib)
+    // column neighbour: one LDS add per lane and component (masked lanes carry zeros: P = 0)
+    if (valid) { TILE_ADD(&L.gd[3 * ib], vb[0]); TILE_ADD(&L.gd[3 * ib + 1], vb[1]); TILE_ADD(&L.gd[3 * ib + 2], vb[2]); }
+    // row neighbour: segmented inclusive scan over the run, inside the lane's 16-lane DPP row
+    float rs[3] = {va[0], va[1], va[2]};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      // the DPP move is executed by every lane (it is a cross-lane read: inside a conditional it would see the lanes the
+      // condition switched off as invalid sources); the condition only selects what is added
+      float t;
+      t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rs[k]), 0x111, 0xf, 0xf, true)); rs[k] += pos >= 1 ? t : 0.f;   // row_shr:1
+      t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rs[k]), 0x112, 0xf, 0xf, true)); rs[k] += pos >= 2 ? t : 0.f;   // row_shr:2
+      t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rs[k]), 0x114, 0xf, 0xf, true)); rs[k] += pos >= 4 ? t : 0.f;   // row_shr:4
+      t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(rs[k]), 0x118, 0xf, 0xf, true)); rs[k] += pos >= 8 ? t : 0.f;   // row_shr:8
+    }
+    // the run ends here (for this DPP row) if the next lane starts a run or lies in the next DPP row
+    const int pos_next = __builtin_amdgcn_update_dpp(0, pos, 0x101, 0xf, 0xf, true);   // row_shl:1: lane 15 of a row reads 0
+    if (valid && pos_next == 0) { TILE_ADD(&L.gd[3 * ia], rs[0]); TILE_ADD(&L.gd[3 * ia + 1], rs[1]); TILE_ADD(&L.gd[3 * ia + 2], rs[2]); }
+  }
+  wave_sync();   // gd is complete
+#else
   int nbk;
   const int nrows_stream = build_row_table<NA, NZ>(p, lane, L, nbk);
   wave_sync();
@@ -1140,6 +1293,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
    wave_sync();   // the tables are rewritten by the next block of rows; after the last block: gd is complete
   }
 
+#endif
   BWD_STAMP(4);   // angular stage
   // ---- the angular neighbours: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d ----
   for (int q = lane; q < nang; q += 64) {
