@@ -718,12 +718,13 @@ __device__ __forceinline__ void build_row_descriptors(FastLds& L, int nbk, int n
 
 template <int NA, int NZ, int NCH>
 __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
-                                               const Loaded<NCH, false, 1>& pf, int lane) {
+                                               const Loaded<NCH, false, 1>& pf, int lane BWD_STAMP_PARAMS) {
   constexpr int NR = 16, Q = 64 / NA;
   for (int e = lane; e < (p.aev_stride >> 2); e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
   int nrad, nang;
   unpack_lists<NCH>(p, a, row, h, pf, lane, L, nrad, nang);
   wave_sync();
+  BWD_STAMP(2);   // unpack
 
   // ---- radial: per species group, lanes = (slot q, shift k) ----
 #ifndef ABLF_NO_RAD
@@ -752,10 +753,12 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
   }
 #endif
 
+  BWD_STAMP(3);   // radial
   // ---- angular ----
   int nbk;
   const int total = build_bucket_table<NA, NZ>(p, lane, L, nbk);
   wave_sync();
+  BWD_STAMP(4);   // bucket table
   float acc[NZ];
 #pragma unroll
   for (int z = 0; z < NZ; z++) acc[z] = 0.f;
@@ -855,11 +858,13 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
   }
   flush();
   wave_sync();
+  BWD_STAMP(5);   // angular
 
   float4* dst = reinterpret_cast<float4*>(a.aev + (long long)row * p.aev_stride);
   const int n4 = p.aev_stride >> 2;
   for (int e = lane; e < n4; e += 64) dst[e] = reinterpret_cast<const float4*>(L.row)[e];
   wave_sync();  // the LDS slice is reused by this wave's next centre
+  BWD_STAMP(6);   // row store
 }
 
 // Persistent waves: wave w handles rows w, w + W, w + 2W, ...  A centre's inputs (header, list chunks, dE/dAEV row: all
@@ -884,7 +889,28 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FWD_MINW) void aev_forward_fast(Ae
   extern __shared__ float4 smem4[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, false, rowf), cap, false, rowf);
+#ifdef ABLB_STAMPS
+  unsigned long long stamp_prev, stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+  const int nw = gridDim.x * kWaves;
+  for (int k = blockIdx.x * kWaves + wave; k < a.kcount; k += nw) {
+    const int row = a.row_list ? __builtin_amdgcn_readfirstlane(a.row_list[a.k0 + k]) : a.k0 + k;
+    const hdr_t hc = load_header(a, row);
+    BWD_STAMP(0);
+    if (hc[0] < 0) continue;
+    Loaded<NCH, false, 1> cur;
+    load_lists(p, a, row, hdr_nrad(hc), hdr_nang(hc), lane, cur);
+    BWD_STAMP(1);
+    forward_centre<NA, NZ, NCH>(p, a, L, row, hc, cur, lane, stamp_prev, stamp_acc);
+    stamp_acc[7] += 1;
+  }
+  if (wave == 0 && lane == 0) {
+    for (int q = 0; q < 7; q++) atomicAdd(&g_bwd_stamps[16 + q], stamp_acc[q]);
+    atomicAdd(&g_bwd_stamps[24], stamp_acc[7]);
+  }
+#else
   ANI_PERSISTENT_LOOP(kWaves, NCH, false, 1, (forward_centre<NA, NZ, NCH>(p, a, L, row, hc, cur, lane)))
+#endif
 }
 
 // coalesced force scatter of `cnt` neighbours whose gradients sit in LDS as g[3*q + k] with atom indices jx[q]:

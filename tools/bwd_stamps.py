@@ -31,4 +31,10 @@ nc = max(buf[8], 1)
 print(f"stamps build: {rc == 2}; centres stamped (wave 0 of each workgroup, {N} steps): {nc}; cycles per centre: {tot / nc:.0f}")
 for k, n in enumerate(names):
     print(f"  {n:55s} {buf[k] / nc:9.0f}  {100.0 * buf[k] / max(tot, 1):5.1f} %")
+fn = ["header load", "list loads", "unpack lists into LDS (+ 2 cos per neighbour)", "radial", "bucket table", "angular (phase 1 + 2 per chunk)", "row store"]
+ftot = sum(buf[16 + k] for k in range(7))
+fc = max(buf[24], 1)
+print(f"forward kernel: centres stamped {fc}; cycles per centre: {ftot / fc:.0f}")
+for k, n in enumerate(fn):
+    print(f"  {n:55s} {buf[16 + k] / fc:9.0f}  {100.0 * buf[16 + k] / max(ftot, 1):5.1f} %")
 ani.close()
