@@ -548,56 +548,84 @@ __device__ __forceinline__ void stream_pair(const FastLds& L, int nbk, int t, in
   ib = e0.w + b;
 }
 
-// Backward, dense pair stream: the forward pass's bucket table without the padding of bucket starts (nothing here needs a
-// bucket to start on a lane multiple).  entry: {tstart, a1, n1, a2, n2, outoff, tri, npairs}; returns the stream length.
+// Backward, dense pair stream in two half-waves.  Lanes 0..31 and 32..63 walk the SAME sequence of 32 "column slots" per
+// step, the lower half on the even row neighbours of a bucket, the upper half on the odd ones: lane l and lane l + 32 hold
+// pairs (a, b) and (a + 1, b) with the same column neighbour b, so a column's gradient leaves the step as ONE LDS add per two
+// pairs (the two halves are summed with a half-wave swap; LDS float adds cost about a cycle per active lane, and at one add
+// per pair they made the LDS, not the vector unit, the busiest part of the CU).  Rows come in BANDS of two: a rectangular
+// bucket (n1 rows x n2 columns; the larger species group is the columns) has ceil(n1 / 2) bands of n2 slots (an odd last row
+// leaves its upper half idle); a triangular one (pairs a < b of n neighbours) has bands k = 0 .. n/2 - 1 of rows 2k, 2k + 1
+// with n - 1 - 2k slots, column b = 2k + 1 + slot -- the upper half idles at slot 0, where its row meets itself -- floor(n^2/4)
+// slots in all.  A water centre: 36 + 36 + 9 = 81 slots = 3 steps for its 153 pairs.
+// Table entry: {vstart, ra, nr, ca, nc, outoff, tri, slots}; returns the number of slots.
 template <int NA, int NZ>
 __device__ __forceinline__ int build_pair_table(const AevParams& p, int lane, FastLds& L, int& nbk) {
   const int nb_all = p.S * (p.S + 1) / 2;
-  int s1 = 0, s2 = 0, np = 0, n1 = 0, n2 = 0;
+  int s1 = 0, s2 = 0, ns = 0, n1 = 0, n2 = 0;
+  bool sw = false;
   if (lane < nb_all) {
     int rem = lane;
     while (rem >= p.S - s1) { rem -= p.S - s1; s1++; }
     s2 = s1 + rem;
     n1 = L.astart[s1 + 1] - L.astart[s1];
     n2 = L.astart[s2 + 1] - L.astart[s2];
-    np = (s1 == s2) ? n1 * (n1 - 1) / 2 : n1 * n2;
+    if (s1 == s2) {
+      ns = (n1 * n1) >> 2;                       // 0 for n1 < 2
+    } else if (n1 > 0 && n2 > 0) {
+      sw = n2 < n1;                              // rows = the smaller group
+      const int nr = sw ? n2 : n1, nc = sw ? n1 : n2;
+      ns = ((nr + 1) >> 1) * nc;
+    }
   }
-  const int incl = wave_incl_scan(np);
-  const unsigned long long m = __ballot(np > 0);
-  if (np > 0) {
+  const int incl = wave_incl_scan(ns);
+  const unsigned long long m = __ballot(ns > 0);
+  if (ns > 0) {
     int* e = L.tb + 8 * lanes_below(m);
-    e[0] = incl - np; e[1] = L.astart[s1]; e[2] = n1; e[3] = L.astart[s2]; e[4] = n2;
-    e[5] = p.radial_len + lane * (NA * NZ); e[6] = (s1 == s2) ? 1 : 0; e[7] = np;
+    e[0] = incl - ns; e[1] = L.astart[sw ? s2 : s1]; e[2] = sw ? n2 : n1; e[3] = L.astart[sw ? s1 : s2]; e[4] = sw ? n1 : n2;
+    e[5] = p.radial_len + lane * (NA * NZ); e[6] = (s1 == s2) ? 1 : 0; e[7] = ns;
   }
   nbk = __popcll(m);
   return __builtin_amdgcn_readlane(incl, 63);
 }
-// lane -> its pair of the dense stream: row neighbour ia, column neighbour ib, the bucket's dE/dAEV block, and pos = the
-// pair's position in its run (the consecutive pairs that share ia).  Lanes past the end: valid = false, pos = 0 (they look
-// like the start of a run of their own and carry a harmless geometry of two distinct neighbours).
-__device__ __forceinline__ void stream_pair_run(const FastLds& L, int nbk, int t, int& ia, int& ib, int& outoff, int& pos, bool& valid) {
+// lane -> its pair: slot v of the stream, half h (0: the band's even row, 1: its odd row).  pos = the pair's position in its
+// run (the consecutive lanes of a half-wave that share the row neighbour ia).  Idle lanes (past the end, an odd last row's
+// upper half, the upper half at a triangular band's first slot): valid = false, pos = 0, and the indices of a harmless pair.
+__device__ __forceinline__ void stream_pair_half(const FastLds& L, int nbk, int v, int h, int& ia, int& ib, int& outoff, int& pos,
+                                                 bool& valid) {
   int e = 0;
   for (int k = 1; k < nbk; k++)
-    if (t >= L.tb[8 * k]) e = k;
-  const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);       // tstart, a1, n1, a2
-  const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);   // n2, outoff, tri, npairs
-  const int u = t - e0.x;
-  valid = nbk > 0 && u < e1.w;
+    if (v >= L.tb[8 * k]) e = k;
+  const int4 e0 = *reinterpret_cast<const int4*>(L.tb + 8 * e);       // vstart, ra, nr, ca
+  const int4 e1 = *reinterpret_cast<const int4*>(L.tb + 8 * e + 4);   // nc, outoff, tri, slots
+  const int u = v - e0.x;
   outoff = e1.y;
   int a = 0, b = 0;
   pos = 0;
+  valid = nbk > 0 && u < e1.w;
   if (valid) {
     if (e1.z) {
-      decode_pair(u, e0.z, a, b);
-      pos = b - a - 1;
+      // band k: the largest k with k (n - k) <= u; closed form + one correction step each way (all quantities < 2^14)
+      const int n = e0.z;
+      const float fn = (float)n;
+      int k = (int)((fn - __builtin_amdgcn_sqrtf(fmaxf(fn * fn - 4.f * (float)u, 0.f))) * 0.5f);
+      k = max(0, min(k, (n >> 1) - 1));
+      if (__mul24(k, n - k) > u) k--;
+      if (__mul24(k + 1, n - k - 1) <= u) k++;
+      const int c = u - __mul24(k, n - k);
+      a = 2 * k + h;
+      b = 2 * k + 1 + c;
+      pos = c - h;
+      valid = h == 0 || c >= 1;
     } else {
-      a = (int)(((float)u + 0.5f) * frcp((float)e1.x));
-      b = u - a * e1.x;
-      pos = b;
+      const int k = (int)(((float)u + 0.5f) * frcp((float)e1.x));
+      const int c = u - k * e1.x;
+      a = 2 * k + h;
+      b = c;
+      pos = c;
+      valid = a < e0.z;
     }
-  } else if (e1.z) {
-    b = 1;  // distinct neighbours keep the padded geometry finite
   }
+  if (!valid) { a = 0; b = e1.z ? 1 : 0; pos = 0; }   // two distinct neighbours of a non-empty bucket (a triangular one has n >= 2)
   ia = e0.y + a;
   ib = e0.w + b;
 }
@@ -1046,14 +1074,14 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   }
   BWD_STAMP(2);   // radial stage incl. the radial-only scatter
 #ifndef ANI_BWD_ROWS
-  // ---- angular, dense pair stream (round 3): the pairs of all non-empty species-pair buckets form ONE stream, bucket after
-  // bucket, pair after pair in row-major order of (row neighbour a, column neighbour b) -- the forward pass's enumeration
-  // without its padding.  A step takes 64 consecutive pairs whatever buckets they belong to: a water centre's 153 pairs are 3
-  // steps (the row layout below, with one 16-lane row per row neighbour, needed 4: 60 % of its lanes held a pair; removing
-  // one step from every centre took 13 % off the kernel).  The pairs that share their ROW neighbour are consecutive lanes (a
-  // run); its gradient is summed over the run by a segmented scan inside each 16-lane DPP row -- level d adds the value d
-  // lanes down if that lane belongs to the same run -- and the last lane of the run in its DPP row adds the partial sum to the
-  // neighbour's LDS accumulator.  The COLUMN neighbour's gradient is one LDS add per lane, as before.
+  // ---- angular, dense pair stream (round 3).  The pairs of all non-empty species-pair buckets form ONE stream, bucket after
+  // bucket, that a step takes 64 lanes of whatever buckets they belong to: a water centre's 153 pairs are 3 steps (the row
+  // layout kept below under ANI_BWD_ROWS, one 16-lane row per row neighbour, needed 4: 60 % of its lanes held a pair).  The
+  // two half-waves walk the stream's column slots together, on two adjacent row neighbours (build_pair_table).  The pairs of
+  // a half-wave that share their ROW neighbour are consecutive lanes (a run): its gradient is summed over the run by a
+  // segmented scan inside each 16-lane DPP row -- level d adds the value d lanes down if that lane belongs to the same run --
+  // and the last lane of the run in its DPP row adds the partial sum to the neighbour's LDS accumulator.  The COLUMN
+  // neighbour's gradient: the two half-waves' values summed with a half-wave swap, one LDS add per lane of the lower half.
   int nbk;
   const int total_pairs = build_pair_table<NA, NZ>(p, lane, L, nbk);
   wave_sync();
@@ -1062,11 +1090,11 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
 #ifdef ABL_NO_ANG
   for (int base = 0; base < 0; base += 64) {
 #else
-  for (int base = 0; base < total_pairs; base += 64) {
+  for (int base = 0; base < total_pairs; base += 32) {
 #endif
     int ia, ib, outoff, pos;
     bool valid;
-    stream_pair_run(L, nbk, base + lane, ia, ib, outoff, pos, valid);
+    stream_pair_half(L, nbk, base + (lane & 31), lane >> 5, ia, ib, outoff, pos, valid);
     const float4 A = L.ad[ia], B = L.ad[ib];
     const float inv_ra = frcp(A.w), inv_rb = frcp(B.w);
     const float inv_rr = inv_ra * inv_rb;
@@ -1124,8 +1152,16 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     const float tb = (Bq + Cq * fa * dfb) * inv_rb - Aq * cosv * inv_rb * inv_rb;
     const float va[3] = {cc * B.x + ta * A.x, cc * B.y + ta * A.y, cc * B.z + ta * A.z};  // d/d(neighbour ia)
     const float vb[3] = {cc * A.x + tb * B.x, cc * A.y + tb * B.y, cc * A.z + tb * B.z};  // d/d(neighbour ib)
-    // column neighbour: one LDS add per lane and component (masked lanes carry zeros: P = 0)
-    if (valid) { TILE_ADD(&L.gd[3 * ib], vb[0]); TILE_ADD(&L.gd[3 * ib + 1], vb[1]); TILE_ADD(&L.gd[3 * ib + 2], vb[2]); }
+    // column neighbour: lanes l and l + 32 hold the same one; masked lanes carry zeros (P = 0), and a valid upper lane has a
+    // valid lower one
+    {
+      const float c0 = xor_sum<32>(vb[0]), c1 = xor_sum<32>(vb[1]), c2 = xor_sum<32>(vb[2]);
+#ifdef ABL_NO_COLADD2
+      asm volatile("" ::"v"(c0), "v"(c1), "v"(c2));
+#else
+      if (valid && lane < 32) { TILE_ADD(&L.gd[3 * ib], c0); TILE_ADD(&L.gd[3 * ib + 1], c1); TILE_ADD(&L.gd[3 * ib + 2], c2); }
+#endif
+    }
     // row neighbour: segmented inclusive scan over the run, inside the lane's 16-lane DPP row
     float rs[3] = {va[0], va[1], va[2]};
 #pragma unroll
