@@ -210,6 +210,9 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *       member writing its own dE/dAEV rows, summed afterwards.  One member and fewer than ~18 000 atoms: the chained per-layer
  *       launch is faster and is used.  2 = the fused kernel whatever the size, 3 = the same with a tile's members one after
  *       the other in its workgroup (tests, measurements).  Takes effect at the next call.
+ *   "mlp_fused_schedule" (default 1): which workgroup of the fused launch runs which tiles is decided on the host, once per
+ *       re-neighbouring, by first-fit-decreasing on the tiles' costs (the smallest makespan that packs them into the CUs);
+ *       0 = the workgroups draw tiles from a counter, costliest first.  Takes effect at the next call.
  *   "mlp_arith" (default 1): how the MLP evaluates its fp32 products; fp32 accumulation in every case, takes effect at
  *       the next call.  1, the exact split, is what the reference's "fp32 with TF32 off" means on this chip; 2 is the
  *       counterpart of its opt-in LAMMPS_ANI_ALLOW_TF32 (src/ani_csrc/ani.cpp:41-43), also selected by that variable.

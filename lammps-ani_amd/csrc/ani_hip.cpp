@@ -117,10 +117,13 @@ struct ani_handle {
   bool prune = true;  // ani_set_option("prune_absent_species")
   int mlp_pipeline = 1;   // ani_set_option("mlp_pipeline"): 1 = large systems run all MLP layers as one launch of persistent workgroups
                           // with per-tile dependencies, 2 = at any size (measurement knob), 0 = one launch per layer
+  int mlp_fused_sched = 1;   // ani_set_option("mlp_fused_schedule"): 1 = static first-fit schedule of the fused launch, 0 = a counter
   int mlp_fused = 1;   // ani_set_option("mlp_fused"): 1 = networks of three hidden layers run as one launch, a 128-row tile per
                        // workgroup with the activations in registers (ani_kernels_mlpf.hip); 0 = the per-layer kernels
   int fused_mask[2] = {-2, -2};   // active_mask the fused streams of each arithmetic were built for
   DevBuf<int> fused_counter;
+  DevBuf<int> fused_sched;    // static schedule of the fused launch: items, then offsets (fused_schedule); remade per list epoch
+  int sched_key[4] = {-1, -1, -1, -1};   // what it was made for: total tiles, items per tile, problems, bins
   DevBuf<float> gaev_parts;   // fused MLP with (tile, member) work items: every member's own dE/dAEV rows
   int mlp_chain = 1;   // ani_set_option("mlp_chain"): 1 = one chained launch for the MLP of small systems, 2 = at any size, 0 = never
   ChainPlan chain_plan;
@@ -657,6 +660,37 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
     G.gaev_parts = h->gaev_parts.p;
     G.part_stride = (long long)per;
   }
+  // which workgroup runs which items: a static schedule, remade when the tile counts change (re-neighbouring)
+  if (h->mlp_fused_sched) {
+    const int per_tile = G.member_items ? m.M : 1, bins = fused_num_cus();
+    const int nitems = total * per_tile;
+    int mix = np;   // the tile counts and shapes of the problems, folded into one word
+    for (int q = 0; q < np; q++) mix = mix * 1000003 + G.p[q].tiles * 4 + G.p[q].shape;
+    if (h->sched_key[0] != total || h->sched_key[1] != per_tile || h->sched_key[2] != mix || h->sched_key[3] != bins || !h->fused_sched.p) {
+      // item types: one per problem; a (tile, member) item costs what its tile's member costs.  Item t of the kernel's numbering
+      // is tile t / per_tile: the items of a problem are contiguous.
+      int cnt[kMaxProblems];
+      double cost[kMaxProblems];
+      for (int q = 0; q < np; q++) {
+        int nt[3];
+        fused_shape_tiles(G.p[q].shape, nt);
+        cnt[q] = G.p[q].tiles * per_tile;
+        cost[q] = (double)G.p[q].ks0 * nt[0] + 4.0 * nt[0] * nt[1] + 4.0 * nt[1] * nt[2] + 2.0 * nt[0] * G.p[q].nt0 +
+                  12.0;   // MFMA blocks of a member + a little for what a tile costs whatever its size
+        if (!G.member_items) cost[q] *= m.M;
+      }
+      std::vector<int> items(std::max(nitems, 1)), off(bins + 1);
+      (void)fused_schedule(np, cnt, cost, bins, items.data(), off.data());
+      HIP_TRY(h, h->fused_sched.reserve((size_t)nitems + bins + 1));
+      HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p, items.data(), sizeof(int) * (size_t)nitems, hipMemcpyHostToDevice, st));
+      HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p + nitems, off.data(), sizeof(int) * (size_t)(bins + 1), hipMemcpyHostToDevice, st));
+      HIP_TRY(h, hipStreamSynchronize(st));   // items / off are locals; once per re-neighbouring
+      h->sched_key[0] = total; h->sched_key[1] = per_tile; h->sched_key[2] = mix; h->sched_key[3] = bins;
+    }
+    G.sched_items = h->fused_sched.p;
+    G.sched_off = h->fused_sched.p + nitems;
+    G.sched_blocks = bins;
+  }
   HIP_TRY(h, launch_mlp_fused(G, arith, st));
   if (G.member_items) launch_sum_parts(h->gaev_parts.p, G.part_stride, m.M, h->gaev.p, (long long)h->nrows * ka, st);
   return ANI_OK;
@@ -1188,7 +1222,7 @@ void ani_destroy(ani_handle* h) {
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();
   free_fused(h, 0); free_fused(h, 1);
-  h->fused_counter.release(); h->gaev_parts.release();
+  h->fused_counter.release(); h->gaev_parts.release(); h->fused_sched.release();
   free_chain_plan(h->chain_plan);
   for (auto& e : h->evt_pool) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1559,6 +1593,11 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   if (strcmp(name, "mlp_fused") == 0) {
     if (value < 0 || value > 3) { h->err = "mlp_fused must be 0, 1, 2 or 3"; return ANI_ERR_ARG; }
     h->mlp_fused = value;
+    return ANI_OK;
+  }
+  if (strcmp(name, "mlp_fused_schedule") == 0) {
+    h->mlp_fused_sched = value != 0;
+    h->sched_key[0] = -1;
     return ANI_OK;
   }
   if (strcmp(name, "mlp_pipeline") == 0) {

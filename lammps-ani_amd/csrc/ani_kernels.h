@@ -115,7 +115,10 @@ struct FusedArgs {
   float* gaev_parts;
   long long part_stride;              // floats per member in gaev_parts (= rows of the whole step x aev_stride)
   float alpha, inv_alpha, scale;      // CELU; scale = 1 / M
-  int* counter;                       // device word the workgroups draw tiles from (zeroed by the launcher)
+  int* counter;                       // device word the workgroups draw tiles from (zeroed by the launcher); unused with a schedule
+  const int* sched_items;             // static schedule (fused_schedule): work items of workgroup b = sched_items[sched_off[b] ..
+  const int* sched_off;               //   sched_off[b + 1]); null: items are drawn from `counter`
+  int sched_blocks;                   // workgroups the schedule was made for (= the grid)
   int* err_flag;                      // device error word: bit 4 = the weight ring's schedule broke (cannot happen: tests/ring_sim.cpp)
 };
 int fused_shape_for(int d1, int d2, int d3);          // -1: no compiled shape holds these widths
@@ -129,6 +132,12 @@ void launch_build_stream(const float* src, int ld, int rows_valid, int k_valid, 
                          unsigned short* dst, hipStream_t st);
 hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st);
 int fused_num_cus();
+// Static schedule of a launch: `nitem_types` kinds of work items (type j: count[j] items of relative cost[j], items numbered
+// type after type), `bins` workgroups.  Multifit: the smallest makespan T for which first-fit-decreasing packs every item into
+// the bins.  items_out[sum count]: item numbers, workgroup after workgroup; off_out[bins + 1].  Returns the makespan.
+// (Drawing items from a counter, costliest first, is list scheduling: at 100 002 water atoms -- 521 + 261 tiles of cost 1 and
+// 0.67 on 256 CUs -- its last 14 tiles start when most CUs have finished, makespan 3.35; first-fit finds 3.0.)
+double fused_schedule(int nitem_types, const int* count, const double* cost, int bins, int* items_out, int* off_out);
 // dst[i] = sum over m < M of parts[m * part_stride + i], i < n (n a multiple of 4, 16-byte aligned pointers)
 void launch_sum_parts(const float* parts, long long part_stride, int M, float* dst, long long n, hipStream_t st);
 // diagnostic builds (-DABLF_STAMPS) only: cycles per phase summed over tiles; returns 0 in the shipped build

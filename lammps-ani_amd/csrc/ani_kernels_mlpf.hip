@@ -34,6 +34,7 @@
 // forward pass; the backward products write each gradient over the activation it is masked with, their source held as
 // 16-bit fragments (g3: 120, g2: 144), so 128 + 96 + 120 + an accumulator while g2 is formed.  One workgroup per CU; tiles
 // are handed out from a counter, costliest species first.
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -700,9 +701,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused(FusedArgs G) {
   cx.m0 = 0; cx.m1 = G.M; cx.parts = nullptr; cx.part_stride = 0;
   const int per_tile = G.member_items ? G.M : 1;   // work items per tile (members side by side: they share the AEV rows in L2)
   const int total = G.tile_start[G.nprob] * per_tile;
+  int sched_pos = 0;
   for (;;) {
     __syncthreads();   // every wave is done with the tile before (ring, constants, s_tile)
-    if (threadIdx.x == 0) s_tile = atomicAdd(G.counter, 1);
+    if (G.sched_items) {   // static schedule: this workgroup's list
+      if (threadIdx.x == 0) {
+        const int i = G.sched_off[blockIdx.x] + sched_pos;
+        s_tile = i < G.sched_off[blockIdx.x + 1] ? G.sched_items[i] : total;
+      }
+      sched_pos++;
+    } else if (threadIdx.x == 0) s_tile = atomicAdd(G.counter, 1);
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(s_tile);
     if (item >= total) break;
@@ -791,11 +799,54 @@ int fused_num_cus() {
   return ncu;
 }
 
+double fused_schedule(int ntypes, const int* count, const double* cost, int bins, int* items_out, int* off_out) {
+  std::vector<int> order(ntypes), first(ntypes + 1, 0);
+  for (int j = 0; j < ntypes; j++) { order[j] = j; first[j + 1] = first[j] + count[j]; }
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  double total = 0.0, cmax = 0.0;
+  for (int j = 0; j < ntypes; j++) { total += count[j] * cost[j]; if (count[j] > 0) cmax = std::max(cmax, cost[j]); }
+  std::vector<int> take((size_t)bins * ntypes), best;
+  auto fits = [&](double T) {
+    std::fill(take.begin(), take.end(), 0);
+    std::vector<double> rem(bins, T);
+    for (int jj = 0; jj < ntypes; jj++) {
+      const int j = order[jj];
+      int left = count[j];
+      if (left == 0 || cost[j] <= 0.0) { if (left) { take[j] += left; } continue; }
+      for (int b = 0; b < bins && left > 0; b++) {
+        const int k = std::min(left, (int)((rem[b] + 1e-9) / cost[j]));
+        if (k > 0) { take[(size_t)b * ntypes + j] = k; rem[b] -= k * cost[j]; left -= k; }
+      }
+      if (left > 0) return false;
+    }
+    return true;
+  };
+  double lo = std::max(total / bins, cmax), hi = lo;
+  while (!fits(hi)) hi *= 1.25;
+  best = take;
+  for (int it = 0; it < 24 && hi - lo > 1e-3 * hi; it++) {
+    const double mid = 0.5 * (lo + hi);
+    if (fits(mid)) { hi = mid; best = take; } else lo = mid;
+  }
+  std::vector<int> next(first.begin(), first.end() - 1);
+  int n = 0;
+  for (int b = 0; b < bins; b++) {
+    off_out[b] = n;
+    for (int jj = 0; jj < ntypes; jj++) {
+      const int j = order[jj];
+      for (int k = 0; k < best[(size_t)b * ntypes + j]; k++) items_out[n++] = next[j]++;
+    }
+  }
+  off_out[bins] = n;
+  return hi;
+}
+
 hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st) {
   const int ncu = fused_num_cus();
   const int total = G.tile_start[G.nprob] * (G.member_items ? G.M : 1);
   if (total <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(G.counter, 0, sizeof(int), st);
+  hipError_t e = hipSuccess;
+  if (!G.sched_items) e = hipMemsetAsync(G.counter, 0, sizeof(int), st);
   if (e != hipSuccess) return e;
   const int pi = arith == MLP_F16X2 ? 1 : 0;
   const void* fn = pi ? (const void*)mlp_fused<2> : (const void*)mlp_fused<3>;
@@ -813,7 +864,7 @@ hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st) 
       raised.insert(std::make_pair(dev, fn));
     }
   }
-  const int grid = total < ncu ? total : ncu;
+  const int grid = G.sched_items ? G.sched_blocks : (total < ncu ? total : ncu);
   if (pi) hipLaunchKernelGGL(mlp_fused<2>, dim3(grid), dim3(256), kFusedLds, st, G);
   else hipLaunchKernelGGL(mlp_fused<3>, dim3(grid), dim3(256), kFusedLds, st, G);
   return hipGetLastError();
