@@ -207,7 +207,7 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *       workgroup takes a 128-row tile through all six products of every member with the activations in registers
  *       (ani_kernels_mlpf.hip); HBM sees the AEV rows and the dE/dAEV rows only.  0 = the per-layer kernels below.  Needs a
  *       split arithmetic ("mlp_arith" 1 or 2).  With several ensemble members a work item is (tile, member), each
- *       member writing its own dE/dAEV rows, summed afterwards.  One member and fewer than ~18 000 atoms: the chained per-layer
+ *       member writing its own dE/dAEV rows, summed afterwards.  One member and fewer than ~16 000 atoms: the chained per-layer
  *       launch is faster and is used.  2 = the fused kernel whatever the size, 3 = the same with a tile's members one after
  *       the other in its workgroup (tests, measurements).  Takes effect at the next call.
  *   "mlp_fused_schedule" (default 1): which workgroup of the fused launch runs which tiles is decided on the host, once per

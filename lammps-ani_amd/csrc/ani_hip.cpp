@@ -524,11 +524,11 @@ bool fused_eligible(const ani_handle* h) {
   if (!h->mlp_fused || h->mlp_arith == MLP_FP32 || m.L != 4) return false;
   // Small systems: a fused tile takes ~0.1 ms whatever else happens, so with fewer tiles than CUs the kernel costs that much
   // however few rows there are, while the chained per-layer launch of small systems scales down with them (MLP, exact
-  // arithmetic: 12 501 atoms 0.098 fused against 0.081 chained; 25 002 atoms 0.102 against 0.121): fused from ~18 000 atoms on.
+  // arithmetic: 12 501 atoms 0.09 fused against 0.08 chained; 25 002 atoms 0.09 against 0.12): fused from ~16 000 atoms on.
   if (h->mlp_fused < 2 && m.M == 1) {   // (several members: the fused kernel's (tile, member) work items win at every size measured)
     int tiles = 0;
     for (int s = 0; s < m.S; s++) tiles += round_up(h->count[s], kRowTile) / kRowTile;
-    if (tiles < 140) return false;
+    if (tiles < 125) return false;
   }
   const int acols = h->ap_run.aev_len;
   if (acols < 16 || (acols & 15) || (h->ap_run.aev_stride & 3)) return false;
