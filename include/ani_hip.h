@@ -261,6 +261,12 @@ void ani_trace_mark(const char* name);
  * (tools/mlpf_stamps.py); returns 0 and writes nothing in the shipped build */
 int ani_debug_fused_stamps(unsigned long long* out16, int reset);
 
+/* development probe (host arithmetic only, no device): the static schedule the fused MLP launch uses ("mlp_fused_schedule") for
+ * ntypes kinds of work items -- count[j] items of relative cost[j], numbered type after type -- on `bins` workgroups:
+ * items_out[sum count] = item numbers, workgroup after workgroup; off_out[bins + 1]; *makespan_out = the largest workgroup load */
+int ani_debug_fused_schedule(int ntypes, const int* count, const double* cost, int bins, int* items_out, int* off_out,
+                             double* makespan_out);
+
 /* copy `bytes` from a device pointer of the view to host memory (synchronises the handle's stream first) */
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes);
 

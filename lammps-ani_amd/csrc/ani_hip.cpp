@@ -1636,6 +1636,26 @@ int ani_debug_fused_stamps(unsigned long long* out32, int reset) {   // 1: fused
   return r ? r : aev_read_stamps(out32, reset);
 }
 
+int ani_debug_fused_schedule(int ntypes, const int* count, const double* cost, int bins, int* items_out, int* off_out,
+                             double* makespan_out) {
+  if (ntypes < 1 || ntypes > kMaxProblems || !count || !cost || bins < 1 || !items_out || !off_out) return ANI_ERR_ARG;
+  for (int j = 0; j < ntypes; j++)
+    if (count[j] < 0 || !(cost[j] > 0.0)) return ANI_ERR_ARG;
+  (void)fused_schedule(ntypes, count, cost, bins, items_out, off_out);
+  if (makespan_out) {
+    std::vector<int> type_of;
+    for (int j = 0; j < ntypes; j++) type_of.insert(type_of.end(), count[j], j);
+    double worst = 0.0;
+    for (int b = 0; b < bins; b++) {
+      double load = 0.0;
+      for (int i = off_out[b]; i < off_out[b + 1]; i++) load += cost[type_of[items_out[i]]];
+      worst = std::max(worst, load);
+    }
+    *makespan_out = worst;
+  }
+  return ANI_OK;
+}
+
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes) {
   if (!h || !d_src || !host_dst) return ANI_ERR_ARG;
   HIP_TRY(h, hipSetDevice(h->device));
