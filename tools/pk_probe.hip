@@ -1,57 +1,68 @@
-// pk_probe.hip — VALU issue rate of v_fma_f32 vs v_pk_fma_f32 on gfx950 (development tool):
-// many waves per SIMD, 16 independent accumulator chains per lane, no memory traffic in the loop.
-//   hipcc -O3 --offload-arch=gfx950 -o pk_probe pk_probe.hip && ./pk_probe
+// pk_probe.hip -- issue rate of v_pk_fma_f32 / v_pk_mul_f32 against v_fma_f32 on gfx950 (one number decides whether packing the
+// AEV kernels' fp32 arithmetic can pay).  Build: hipcc --offload-arch=gfx950 -O3 -o pk_probe pk_probe.hip ; run: ./pk_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-__global__ __launch_bounds__(256) void k_scalar(float* out, float a, float b, int iters) {
-  float acc[16];
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define REP 64
+template <int MODE>
+__global__ __launch_bounds__(1024) void probe(float* out, unsigned long long* cyc, float seed) {
+  v2f a[8], b[8], c[8];
+  for (int i = 0; i < 8; i++) { a[i] = v2f{seed + i, seed - i}; b[i] = v2f{1.0f + 1e-7f * i, 1.0f - 1e-7f * i}; c[i] = v2f{1e-9f * threadIdx.x, 2e-9f}; }
+  unsigned long long t0, t1;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int r = 0; r < REP; r++) {
 #pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = threadIdx.x * 1e-3f + i;
-  for (int it = 0; it < iters; it++) {
+    for (int u = 0; u < 4; u++) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = __builtin_fmaf(acc[i], a, b);
-  }
-  float s = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) s += acc[i];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-__global__ __launch_bounds__(256) void k_packed(float* out, float a, float b, int iters) {
-  f2 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) acc[i] = (f2){threadIdx.x * 1e-3f + i, threadIdx.x * 2e-3f + i};
-  const f2 av = {a, a}, bv = {b, b};
-  for (int it = 0; it < iters; it++) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = __builtin_elementwise_fma(acc[i], av, bv);
-  }
-  float s = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) s += acc[i].x + acc[i].y;
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-
-int main() {
-  float* out; hipMalloc(&out, 4 * 256 * 256 * 16);
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int iters = 20000;
-  for (int blocks_per_cu : {1, 2, 4, 8}) {
-    const int grid = 256 * blocks_per_cu;
-    for (int v = 0; v < 2; v++) {
-      for (int w = 0; w < 2; w++) {
-        if (w) hipEventRecord(e0, 0);
-        if (v == 0) hipLaunchKernelGGL(k_scalar, dim3(grid), dim3(256), 0, 0, out, 0.999f, 0.001f, iters);
-        else hipLaunchKernelGGL(k_packed, dim3(grid), dim3(256), 0, 0, out, 0.999f, 0.001f, iters);
-        if (w) { hipEventRecord(e1, 0); hipEventSynchronize(e1); }
+      for (int i = 0; i < 8; i++) {
+        if (MODE == 0) {   // 16 scalar fma: three distinct VGPR sources
+          asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].x) : "v"(b[i].x), "v"(c[i].x));
+          asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].y) : "v"(b[i].y), "v"(c[i].y));
+        } else if (MODE == 1) {   // 8 packed fma, three distinct VGPR pairs
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]));
+        } else if (MODE == 2) {   // packed fma, two sources the same pair
+          asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(a[i]) : "v"(b[i]));
+        } else if (MODE == 3) {   // packed mul
+          asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
+        } else if (MODE == 4) {   // scalar mul x2
+          asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[i].x) : "v"(b[i].x), "v"(c[i].x));
+          asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[i].y) : "v"(b[i].y), "v"(c[i].y));
+        } else if (MODE == 5) {   // packed fma with a broadcast source (op_sel_hi 0 on src0)
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]));
+        } else if (MODE == 6) {   // packed add
+          asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
+        }
       }
-      float ms; hipEventElapsedTime(&ms, e0, e1);
-      const double fma = (double)grid * 256 * 16 * iters;   // scalar-equivalent FMAs
-      printf("%s  %d waves/SIMD: %.3f ms  %.1f TFLOP/s  (%.2f cycles at 2.4 GHz per wave-instruction)\n", v ? "v_pk_fma_f32" : "v_fma_f32   ",
-             blocks_per_cu, ms, 2 * fma / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)iters * (v ? 8 : 16) * blocks_per_cu));
     }
+  }
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  float s = 0.f;
+  for (int i = 0; i < 8; i++) s += a[i].x + a[i].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) atomicMax(cyc, t1 - t0);   // the slowest wave: the issue arbiter favours the oldest one
+}
+template <int MODE>
+static void run(const char* name, int threads, int ninstr_per_iter) {
+  float* out; unsigned long long* cyc;
+  hipMalloc(&out, 1 << 20); hipMalloc(&cyc, 8);
+  hipLaunchKernelGGL(probe<MODE>, dim3(1), dim3(threads), 0, 0, out, cyc, 1.0f);
+  hipDeviceSynchronize(); hipMemset(cyc, 0, 8);
+  hipLaunchKernelGGL(probe<MODE>, dim3(1), dim3(threads), 0, 0, out, cyc, 1.0f);
+  unsigned long long h; if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { printf("launch failed\n"); return; } hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+  const double n = (double)REP * 4 * ninstr_per_iter;
+  // s_memtime counts at 100 MHz; print raw ticks per instruction per wave-on-a-SIMD as a RATIO between modes
+  printf("%-44s threads %4d  ticks %8llu  ticks/instr %.4f  waves/SIMD %d\n", name, threads, h, h / n, threads / 256 ? threads / 256 : 1);
+  hipFree(out); hipFree(cyc);
+}
+int main() {
+  for (int threads : {256, 512, 1024}) {
+    run<0>("v_fma_f32 x16 (per 8 pairs)", threads, 16);
+    run<1>("v_pk_fma_f32 x8, distinct sources", threads, 8);
+    run<2>("v_pk_fma_f32 x8, src0 == src1", threads, 8);
+    run<5>("v_pk_fma_f32 x8, broadcast src0", threads, 8);
+    run<4>("v_mul_f32 x16", threads, 16);
+    run<3>("v_pk_mul_f32 x8", threads, 8);
+    run<6>("v_pk_add_f32 x8", threads, 8);
   }
   return 0;
 }
