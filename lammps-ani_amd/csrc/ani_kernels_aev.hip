@@ -164,6 +164,18 @@ void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_
 // =====================================================================================================
 // fast path
 // =====================================================================================================
+// The backward kernel's per-neighbour gradient accumulators in LDS take several adds per pair.  On gfx950 an LDS fp32 add
+// (ds_add_f32, also ds_pk_add_f16) is executed ONE LANE AT A TIME, ~3 cycles per active lane -- 192 cycles for a full wave,
+// the CU's LDS blocked meanwhile -- whereas ds_add_f64 takes 8 cycles per wave-instruction, like the integer adds
+// (tools/lds_atomic_probe.hip, profiles/r03_lds_atomic_probe.log).  So the accumulators are doubles: one v_cvt_f64_f32 per
+// value added, 6 instead of 3 words per neighbour, and sums that are more accurate on top.
+#ifdef ANI_GD_F32
+typedef float gd_t;
+#else
+typedef double gd_t;
+#endif
+constexpr int kGdWords = 3 * (int)(sizeof(gd_t) / 4);   // LDS words per angular neighbour
+
 struct FastLds {
   // carved from dynamic LDS, per wave
   float4* ad;     // [kMaxAng] angular neighbours dx,dy,dz,r
@@ -177,7 +189,7 @@ struct FastLds {
   float* rr;      // [cap] forward: radial list r
   float* rfc;     // [cap] forward: fc(r; Rcr)
   int* aj;        // [kMaxAng] backward: atom index of the angular neighbours
-  float* gd;      // [3*kMaxAng] backward: dE/d(displacement) of the angular neighbours
+  gd_t* gd;       // [3*kMaxAng] backward: dE/d(displacement) of the angular neighbours (fp64: see gd_t)
   float* gt;      // [3*64] backward: staging of one chunk of radial-only gradients for the force scatter
   int* jt;        // [64]   ... and of their atom indices
   int4* rowd;     // [2*32] backward: descriptors of 32 rows of the pair stream (build_row_descriptors)
@@ -199,7 +211,7 @@ __host__ __device__ constexpr int fast_wave_floats(int cap, bool bwd) {
   // forward adds the phase-1 factor buffers pf (64*12) and r, fc per radial neighbour;
   // backward adds aj, gd[3] per ANGULAR neighbour, the 4*64 staging words (the radial-only neighbours never touch LDS)
   // and the descriptors (8 words) of 32 rows of the pair stream at a time
-  return 5 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? 4 * kMaxAng + 256 + 256 + kParkWords : 64 * 12 + 2 * cap);
+  return 5 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? (1 + kGdWords) * kMaxAng + 256 + 256 + kParkWords : 64 * 12 + 2 * cap);
 }
 // same with the AEV row sized for the columns actually in use (rowf floats, multiple of 64)
 __host__ __device__ constexpr int fast_wave_floats_row(int cap, bool bwd, int rowf) {
@@ -224,7 +236,7 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
     L.rfc = p; p += cap;
   } else {
     L.aj = reinterpret_cast<int*>(p); p += kMaxAng;
-    L.gd = p; p += 3 * kMaxAng;
+    L.gd = reinterpret_cast<gd_t*>(p); p += kGdWords * kMaxAng;   // 8-byte aligned: every piece in front of it is an even number of words
     L.gt = p; p += 3 * 64;
     L.jt = reinterpret_cast<int*>(p); p += 64;
     L.rowd = reinterpret_cast<int4*>(p); p += 256;
@@ -633,7 +645,7 @@ __device__ __forceinline__ void stream_pair_half(const FastLds& L, int nbk, int 
 #ifdef ABL_NO_TWRITE
 #define TILE_ADD(p, v) asm volatile("" ::"v"(p), "v"(v))
 #else
-#define TILE_ADD(p, v) atomicAdd(p, v)
+#define TILE_ADD(p, v) atomicAdd(p, (gd_t)(v))
 #endif
 // v + v[lane ^ OFF] without an LDS round trip: OFF = 1, 2, 4, 8 as DPP moves inside a row of 16 lanes, OFF = 16 / 32
 // with the gfx950 row / half-wave swaps (both operands the same register: one result holds the even rows or the lower
@@ -794,20 +806,36 @@ __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs
   const int la = lane % NA, lq = lane / NA;
   const float cA = -p.EtaA * kLog2e;
 
+  // A bucket's sums over the 64 / NA slot lanes of each shift.  Cross-lane moves are the expensive vector instructions here
+  // (tools/issue_probe.hip: a half-wave or row swap takes the issue time of ~5 fp32 FMAs, a DPP move of ~3), so the NZ values
+  // are not reduced one by one (NZ x 3..4 levels): each swap level HALVES the number of values a lane carries -- the pair
+  // (acc[i], acc[i + NZ/2]) goes through ONE v_permlane32_swap whose two results add up to the lower half-wave's total of
+  // acc[i] in the lower lanes and the upper half-wave's total of acc[i + NZ/2] in the upper ones; the same with the row swap
+  // -- and the lane bits above the shift index end up selecting the section: lane = (z, [spare bit,] shift).
   auto flush = [&]() {
     if (cur_off >= 0) {
+      float t[NZ / 2];
 #pragma unroll
-      for (int z = 0; z < NZ; z++) {
-        float v = acc[z];
-        if constexpr (NA <= 4) v = xor_sum<4>(v);
-        if constexpr (NA <= 8) v = xor_sum<8>(v);
-        v = xor_sum<32>(xor_sum<16>(v));
-        acc[z] = v;
+      for (int i = 0; i < NZ / 2; i++) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[i + NZ / 2]), false, false);
+        t[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
       }
-      if (lq == 0) {
+      float u[NZ / 4];
 #pragma unroll
-        for (int z = 0; z < NZ; z++) L.row[cur_off + la * NZ + z] = acc[z];
+      for (int i = 0; i < NZ / 4; i++) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t[i]), __float_as_uint(t[i + NZ / 4]), false, false);
+        u[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
       }
+      float v;
+      if constexpr (NA == 8) {        // NZ = 4: lane = (z: 2 bits, spare bit 3, shift: 3 bits)
+        v = xor_sum<8>(u[0]);
+      } else {                        // NA = 4, NZ = 8: lane = (z: 3 bits, spare bit 2, shift: 2 bits)
+        const bool odd = lane & 8;
+        const float keep = odd ? u[1] : u[0], send = odd ? u[0] : u[1];
+        v = keep + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0x128, 0xf, 0xf, true));   // row_ror:8
+        v = xor_sum<4>(v);
+      }
+      if ((lane & NA) == 0) L.row[cur_off + la * NZ + (lane >> (NA == 8 ? 4 : 3))] = v;
     }
 #pragma unroll
     for (int z = 0; z < NZ; z++) acc[z] = 0.f;
@@ -946,11 +974,12 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FWD_MINW) void aev_forward_fast(Ae
 // instruction.  Global float atomics execute at the memory side as 64-byte requests (MI355X_MICROARCH.md): three
 // separate instructions per neighbour were three requests, this is one, and atoms adjacent both in memory and in the
 // (spatially ordered) list share requests too.
-__device__ __forceinline__ void scatter_neighbours(const AevArgs& a, const float* g, const int* jx, int cnt, int lane) {
+template <typename T>
+__device__ __forceinline__ void scatter_neighbours(const AevArgs& a, const T* g, const int* jx, int cnt, int lane) {
 #ifndef ABL_NO_GATOM
   for (int base = 0; base < cnt; base += 16) {
     const int q = base + (lane >> 2), k = lane & 3;
-    if (q < cnt && k < 3) atomicAdd(&a.fbuf[4 * jx[q] + k], -g[3 * q + k]);
+    if (q < cnt && k < 3) atomicAdd(&a.fbuf[4 * jx[q] + k], -(float)g[3 * q + k]);
   }
 #endif
 }
@@ -1359,7 +1388,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   BWD_STAMP(4);   // angular stage
   // ---- the angular neighbours: F_j -= gd_j ; F_i += sum_j gd_j ; virial -= gd (x) d ----
   for (int q = lane; q < nang; q += 64) {
-    const float gx = L.gd[3 * q], gy = L.gd[3 * q + 1], gz = L.gd[3 * q + 2];
+    const float gx = (float)L.gd[3 * q], gy = (float)L.gd[3 * q + 1], gz = (float)L.gd[3 * q + 2];
     fx += gx; fy += gy; fz += gz;
     if constexpr (VIR) {
       // virial: per-lane partial sums kept across all the centres of this wave; the nine totals are reduced over the

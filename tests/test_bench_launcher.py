@@ -25,7 +25,9 @@ def test_parent_launches_two_ranks_that_reach_the_device_check():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"ANI_BENCH_BACKEND": "gloo"})
     assert r.returncode != 0
     assert r.stdout.strip() == ""                       # no JSON line from a failed run
-    assert r.stderr.count("no HIP device visible") == 2   # both ranks were started and got to the device check
+    # the ranks were started and got to the device check: both normally, but the launcher ends the second rank as soon as
+    # the first has failed, so on a slow start only one message may make it out
+    assert 1 <= r.stderr.count("no HIP device visible") <= 2
     assert "SystemExit: --gpus" not in r.stderr and "must be launched with" not in r.stderr
 
 

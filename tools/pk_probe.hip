@@ -42,16 +42,16 @@ __global__ __launch_bounds__(1024) void probe(float* out, unsigned long long* cy
   if ((threadIdx.x & 63) == 0) atomicMax(cyc, t1 - t0);   // the slowest wave: the issue arbiter favours the oldest one
 }
 template <int MODE>
-static void run(const char* name, int threads, int ninstr_per_iter) {
+static void run(const char* name, int threads, int ninstr_per_iter, int blocks = 1) {
   float* out; unsigned long long* cyc;
-  hipMalloc(&out, 1 << 20); hipMalloc(&cyc, 8);
-  hipLaunchKernelGGL(probe<MODE>, dim3(1), dim3(threads), 0, 0, out, cyc, 1.0f);
+  hipMalloc(&out, (size_t)4 * 1024 * 1024); hipMalloc(&cyc, 8);
+  hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.0f);
   hipDeviceSynchronize(); hipMemset(cyc, 0, 8);
-  hipLaunchKernelGGL(probe<MODE>, dim3(1), dim3(threads), 0, 0, out, cyc, 1.0f);
+  hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(threads), 0, 0, out, cyc, 1.0f);
   unsigned long long h; if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { printf("launch failed\n"); return; } hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
   const double n = (double)REP * 4 * ninstr_per_iter;
   // s_memtime counts at 100 MHz; print raw ticks per instruction per wave-on-a-SIMD as a RATIO between modes
-  printf("%-44s threads %4d  ticks %8llu  ticks/instr %.4f  waves/SIMD %d\n", name, threads, h, h / n, threads / 256 ? threads / 256 : 1);
+  printf("%-44s threads %4d  ticks %8llu  ticks/instr %.4f  waves/SIMD %d  cycles per wave-instruction and SIMD %.3f\n", name, threads, h, h / n, blocks > 1 ? 8 : threads / 256, h / n / (blocks > 1 ? 8 : threads / 256));
   hipFree(out); hipFree(cyc);
 }
 int main() {
@@ -64,5 +64,10 @@ int main() {
     run<3>("v_pk_mul_f32 x8", threads, 8);
     run<6>("v_pk_add_f32 x8", threads, 8);
   }
+  // two workgroups of 16 waves per CU: 8 waves per SIMD (the slowest wave of the whole grid)
+  run<0>("v_fma_f32 x16, 512 workgroups", 1024, 16, 512);
+  run<1>("v_pk_fma_f32 x8, 512 workgroups", 1024, 8, 512);
+  run<4>("v_mul_f32 x16, 512 workgroups", 1024, 16, 512);
+  run<3>("v_pk_mul_f32 x8, 512 workgroups", 1024, 8, 512);
   return 0;
 }
