@@ -1036,6 +1036,36 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       const float fc = 0.5f * fcos_rev(r * rev) + 0.5f;
       const float dfc = -0.5f * p.pi_over_Rcr * fsin_rev(r * rev);
       float dEdr = 0.f;
+#ifndef ANI_RAD_NOREC
+      // The sixteen Gaussians exp2(cR (r - ShfR_k)^2) from six exponentials: in each half of the shifts, around its midpoint
+      // sc, d_k = dc - m Delta (m = k - 3.5) and exp2(cR d_k^2) = E H^(2m) C_|m| with E = exp2(cR dc^2), H = exp2(-cR dc Delta),
+      // C_m = exp2(cR m^2 Delta^2) (wave-uniform).  A transcendental takes the issue time of ~5 FMAs (tools/issue_probe.hip).
+      // E H^(2m) <= 1 / C_m; when E underflows, the half's largest term is below exp(-EtaR (|dc| - 3.5 Delta)^2) ~ 1e-12.
+      {
+        const float cd = cR * p.dShfR * p.dShfR;
+        const float C0 = fexp2(0.25f * cd), C1 = fexp2(2.25f * cd), C2 = fexp2(6.25f * cd), C3 = fexp2(12.25f * cd);
+        const float kf = -2.f * p.EtaR * fc;
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+          const float dc = r - (p.ShfR0 + (3.5f + 8.f * hf) * p.dShfR);
+          const float x = cR * dc;
+          const float E = fexp2(x * dc), H = fexp2(-x * p.dShfR), Hi = fexp2(x * p.dShfR);
+          const float R = H * H, Ri = Hi * Hi;
+          float e[8];
+          float up = E * H, dn = E * Hi;
+          e[4] = up * C0; up *= R; e[5] = up * C1; up *= R; e[6] = up * C2; up *= R; e[7] = up * C3;
+          e[3] = dn * C0; dn *= Ri; e[2] = dn * C1; dn *= Ri; e[1] = dn * C2; dn *= Ri; e[0] = dn * C3;
+          const float4 ga = gg4[2 * hf], gb = gg4[2 * hf + 1];
+          const float gk[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+          float dr = dc + 3.5f * p.dShfR;   // r - ShfR[8 hf]
+#pragma unroll
+          for (int kk = 0; kk < 8; kk++) {
+            dEdr = fmaf(gk[kk] * e[kk], fmaf(kf, dr, dfc), dEdr);
+            dr -= p.dShfR;
+          }
+        }
+      }
+#else
       float dr = r - p.ShfR0;   // equidistant shifts
 #pragma unroll
       for (int k4 = 0; k4 < NR / 4; k4++) {
@@ -1048,6 +1078,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
           dr -= p.dShfR;
         }
       }
+#endif
       const float sc = 0.25f * dEdr * frcp(r);
       gx = sc * v.x; gy = sc * v.y; gz = sc * v.z;
       if (rep.on && r < rep.cutoff) {
@@ -1181,14 +1212,19 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     const float tb = (Bq + Cq * fa * dfb) * inv_rb - Aq * cosv * inv_rb * inv_rb;
     const float va[3] = {cc * B.x + ta * A.x, cc * B.y + ta * A.y, cc * B.z + ta * A.z};  // d/d(neighbour ia)
     const float vb[3] = {cc * A.x + tb * B.x, cc * A.y + tb * B.y, cc * A.z + tb * B.z};  // d/d(neighbour ib)
-    // column neighbour: lanes l and l + 32 hold the same one; masked lanes carry zeros (P = 0), and a valid upper lane has a
-    // valid lower one
+    // column neighbour: lanes l and l + 32 hold the same one
     {
+#ifndef ANI_COL_SWAP
+      // one fp64 LDS add per lane and component (the two half-waves' lanes l, l + 32 share the address: a two-way conflict costs
+      // less than the half-wave swap-add that used to halve the number of slow fp32 adds)
+      if (valid) { TILE_ADD(&L.gd[3 * ib], vb[0]); TILE_ADD(&L.gd[3 * ib + 1], vb[1]); TILE_ADD(&L.gd[3 * ib + 2], vb[2]); }
+#else
       const float c0 = xor_sum<32>(vb[0]), c1 = xor_sum<32>(vb[1]), c2 = xor_sum<32>(vb[2]);
 #ifdef ABL_NO_COLADD2
       asm volatile("" ::"v"(c0), "v"(c1), "v"(c2));
 #else
       if (valid && lane < 32) { TILE_ADD(&L.gd[3 * ib], c0); TILE_ADD(&L.gd[3 * ib + 1], c1); TILE_ADD(&L.gd[3 * ib + 2], c2); }
+#endif
 #endif
     }
     // row neighbour: segmented inclusive scan over the run, inside the lane's 16-lane DPP row
@@ -1707,6 +1743,16 @@ int aev_read_stamps(unsigned long long* out32, int reset) {
 // =====================================================================================================
 static int fast_kind(const AevParams& p) {
   if (p.nR != 16 || p.S > 8 || (p.aev_stride & 3) || !p.equi) return 0;
+  {
+    // the backward kernel's radial Gaussians come from a recurrence around the midpoints of the two halves of the shifts
+    // (backward_centre): its ratio H^2 = exp(2 EtaR dc Delta) must stay inside fp32 for every r in (0, Rcr], 1 / C_3.5 =
+    // exp(EtaR (3.5 Delta)^2) too, and where E = exp(-EtaR dc^2) underflows the half's largest term must be negligible.
+    // Parameter sets beyond that take the generic kernels.
+    const float d = fabsf(p.dShfR), c0 = p.ShfR0 + 3.5f * p.dShfR, c1 = p.ShfR0 + 11.5f * p.dShfR;
+    const float dmax = fmaxf(fmaxf(fabsf(p.Rcr - c0), fabsf(c0)), fmaxf(fabsf(p.Rcr - c1), fabsf(c1)));
+    const float q = sqrtf(87.f / p.EtaR) - 3.5f * d;
+    if (2.f * p.EtaR * dmax * d > 80.f || p.EtaR * 12.25f * d * d > 80.f || q <= 0.f || p.EtaR * q * q < 20.f) return 0;
+  }
   if (p.nA == 8 && p.nZ == 4) return 1;
   if (p.nA == 4 && p.nZ == 8) return 2;
   return 0;
