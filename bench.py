@@ -456,10 +456,10 @@ def main():
         bwd_roof = dict(bound="hbm", achieved=bb / (t_bwd * 1e-3) / 1e9 if t_bwd > 0 else None, peak=PEAK_HBM_GBS, unit="GB/s",
                         traffic=hbm_traffic("ani::aev_backward"), kernel="aev_backward_fast", ms_per_launch=t_bwd, bytes_per_launch=bb,
                         valu_frac=valu("ani::aev_backward", t_bwd), valu_frac_4cyc=valu4("ani::aev_backward", t_bwd),
-                        note="bound by the CU's vector unit (and, next, its LDS), not by HBM (DESIGN.md 3.1): ~1500 VALU wave-instructions "
-                             "per centre, the vector unit active 93 % of the kernel's cycles (SQ_ACTIVE_INST_VALU x 4 / SQ_WAVE_CYCLES), "
-                             "the LDS 69 %; valu_frac = SQ_INSTS_VALU x 2.4 cycles / (1024 SIMDs x time x 2.4 GHz), valu_frac_4cyc the "
-                             "same at the 4 cycles per instruction these kernels are seen to issue at",
+                        note="bound by the CUs' vector issue (and, next, their LDS), not by HBM (DESIGN.md 3.1): ~1480 VALU "
+                             "wave-instructions per centre, a fifth of them transcendentals, DPP moves and half-wave swaps that hold "
+                             "the issue 3-5x as long as an FMA (tools/issue_probe.hip); valu_frac = SQ_INSTS_VALU x 2.4 cycles / "
+                             "(1024 SIMDs x time x 2.4 GHz), valu_frac_4cyc the same at 4 cycles per instruction",
                         counters=pmc_note)
         bwd_roof["frac"] = bwd_roof["achieved"] / PEAK_HBM_GBS if bwd_roof["achieved"] else None
         t_f = t_fwd + t_cmp
