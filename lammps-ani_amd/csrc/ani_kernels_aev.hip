@@ -206,12 +206,17 @@ constexpr int kParkWords = 0;
 #define ANI_ROW_W 16
 #endif
 constexpr int kRowW = ANI_ROW_W;
+#ifdef ANI_BWD_ROWS
+constexpr int kRowdWords = 256;   // descriptors of 32 rows of the row-layout pair stream
+#else
+constexpr int kRowdWords = 0;
+#endif
 __host__ __device__ constexpr int fast_wave_floats(int cap, bool bwd) {
-  // both: ad 4*kMaxAng + afc kMaxAng + row kAevMax + tb kMaxBuckets*8 + starts 2*24
-  // forward adds the phase-1 factor buffers pf (64*12) and r, fc per radial neighbour;
-  // backward adds aj, gd[3] per ANGULAR neighbour, the 4*64 staging words (the radial-only neighbours never touch LDS)
-  // and the descriptors (8 words) of 32 rows of the pair stream at a time
-  return 5 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? (1 + kGdWords) * kMaxAng + 256 + 256 + kParkWords : 64 * 12 + 2 * cap);
+  // both: ad 4*kMaxAng + row kAevMax + tb kMaxBuckets*8 + starts 2*24
+  // forward adds afc, the phase-1 factor buffers pf (64*12) and r, fc per radial neighbour;
+  // backward adds afc, aj and gd[3] (fp64) per ANGULAR neighbour and the 4*64 staging words (the radial-only neighbours never
+  // touch LDS)
+  return 4 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? (2 + kGdWords) * kMaxAng + 256 + kRowdWords + kParkWords : kMaxAng + 64 * 12 + 2 * cap);
 }
 // same with the AEV row sized for the columns actually in use (rowf floats, multiple of 64)
 __host__ __device__ constexpr int fast_wave_floats_row(int cap, bool bwd, int rowf) {
@@ -225,10 +230,10 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
   // fixed-size pieces first so that their offsets from the wave base are compile-time immediates
   L.ad = reinterpret_cast<float4*>(p); p += 4 * kMaxAng;
   L.tb = reinterpret_cast<int*>(p); p += kMaxBuckets * 8;
-  L.afc = p; p += kMaxAng;
   L.rstart = reinterpret_cast<int*>(p); p += 24;
   L.astart = reinterpret_cast<int*>(p); p += 24;
   if (!bwd) {
+    L.afc = p; p += kMaxAng;
     L.pf2 = p; p += 64 * NA;
     L.pf1 = p; p += 64 * NZ;
     L.row = p; p += rowf;
@@ -237,9 +242,12 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
   } else {
     L.aj = reinterpret_cast<int*>(p); p += kMaxAng;
     L.gd = reinterpret_cast<gd_t*>(p); p += kGdWords * kMaxAng;   // 8-byte aligned: every piece in front of it is an even number of words
+    L.afc = p; p += kMaxAng;
     L.gt = p; p += 3 * 64;
     L.jt = reinterpret_cast<int*>(p); p += 64;
+#ifdef ANI_BWD_ROWS
     L.rowd = reinterpret_cast<int4*>(p); p += 256;
+#endif
 #ifdef ANI_PARK_ROWS
     L.rowacc = reinterpret_cast<float4*>(p); p += 256;
 #endif
