@@ -219,8 +219,11 @@ __host__ __device__ constexpr int fast_wave_floats(int cap, bool bwd) {
   return 4 * kMaxAng + kAevMax + kMaxBuckets * 8 + 48 + (bwd ? (2 + kGdWords) * kMaxAng + 256 + kRowdWords + kParkWords : kMaxAng + 64 * 12 + 2 * cap);
 }
 // same with the AEV row sized for the columns actually in use (rowf floats, multiple of 64)
-__host__ __device__ constexpr int fast_wave_floats_row(int cap, bool bwd, int rowf) {
-  return fast_wave_floats(cap, bwd) - kAevMax + rowf;
+// ... and the bucket table for the species pairs of the model in use (S (S + 1) / 2 entries of 8 words: 3 for pruned water, 28 for
+// seven species): the 264 words a water run does not need are the difference between five and six forward workgroups per CU
+__host__ __device__ constexpr int table_words(int S) { return 8 * (S * (S + 1) / 2); }
+__host__ __device__ constexpr int fast_wave_floats_row(int cap, bool bwd, int rowf, int S) {
+  return fast_wave_floats(cap, bwd) - kAevMax + rowf - kMaxBuckets * 8 + table_words(S);
 }
 
 template <int NA, int NZ>
@@ -229,7 +232,6 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
   float* p = base;
   // fixed-size pieces first so that their offsets from the wave base are compile-time immediates
   L.ad = reinterpret_cast<float4*>(p); p += 4 * kMaxAng;
-  L.tb = reinterpret_cast<int*>(p); p += kMaxBuckets * 8;
   L.rstart = reinterpret_cast<int*>(p); p += 24;
   L.astart = reinterpret_cast<int*>(p); p += 24;
   if (!bwd) {
@@ -239,6 +241,7 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
     L.row = p; p += rowf;
     L.rr = p; p += cap;
     L.rfc = p; p += cap;
+    L.tb = reinterpret_cast<int*>(p);   // sized by the model's species count (table_words): last
   } else {
     L.aj = reinterpret_cast<int*>(p); p += kMaxAng;
     L.gd = reinterpret_cast<gd_t*>(p); p += kGdWords * kMaxAng;   // 8-byte aligned: every piece in front of it is an even number of words
@@ -252,6 +255,7 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
     L.rowacc = reinterpret_cast<float4*>(p); p += 256;
 #endif
     L.row = p; p += rowf;
+    L.tb = reinterpret_cast<int*>(p);
   }
   return L;
 }
@@ -952,7 +956,7 @@ template <int NA, int NZ, int NCH>
 __global__ __launch_bounds__(64 * kWaves, ANI_FWD_MINW) void aev_forward_fast(AevParams p, AevArgs a, int cap, int rowf) {
   extern __shared__ float4 smem4[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, false, rowf), cap, false, rowf);
+  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, false, rowf, p.S), cap, false, rowf);
 #ifdef ABLB_STAMPS
   unsigned long long stamp_prev, stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -1457,7 +1461,7 @@ template <int NA, int NZ, int NCH, int GR, bool VIR>
 __global__ __launch_bounds__(64 * kWavesB, ANI_BWD_MINW) void aev_backward_fast(AevParams p, AevArgs a, int cap, int rowf, RepTab rep) {
   extern __shared__ float4 smem4[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, true, rowf), cap, true, rowf);
+  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, true, rowf, p.S), cap, true, rowf);
   float wv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // this lane's share of the wave's virial
   float er = 0.f;                                                // ... and of its repulsion energy
 #ifdef ABLB_STAMPS
@@ -1868,7 +1872,7 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
     if (a.kcount <= 0) return;   // an empty range of rows
     const int cap = radial_cap(p, max_numneigh);
     const int rowf = (p.aev_stride + 63) / 64 * 64;
-    const size_t lds = (size_t)fast_wave_floats_row(cap, false, rowf) * 4 * kWaves;
+    const size_t lds = (size_t)fast_wave_floats_row(cap, false, rowf, p.S) * 4 * kWaves;
     // 64-entry chunks of the radial-only stream prefetched per centre: 1 with the radial screen on (more than 64
     // neighbours between Rca and Rcr are loaded in place), 3 in pyaev mode where every candidate stays
     const bool k1 = fast_kind(p) == 1, n2 = !p.compat;
@@ -1890,7 +1894,7 @@ bool launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
     if (a.kcount <= 0) return true;
     const int cap = radial_cap(p, max_numneigh);
     const int rowf = (p.aev_stride + 63) / 64 * 64;
-    const size_t lds = (size_t)fast_wave_floats_row(cap, true, rowf) * 4 * kWavesB;
+    const size_t lds = (size_t)fast_wave_floats_row(cap, true, rowf, p.S) * 4 * kWavesB;
     const bool k1 = fast_kind(p) == 1, n2 = !p.compat, g1 = p.aev_stride <= 256;
 #define ANI_BWD_CASE(NA, NZ, NCH, GR)                                                                   \
   do {                                                                                                  \
