@@ -119,6 +119,24 @@ def test_hip_water_1500_against_oracle(model_cache, hip):
     ani.close()
 
 
+@pytest.mark.parametrize("eta_r", [12.0, 30.0, 80.0], ids=["wide", "narrow", "beyond-the-guard"])
+def test_hip_radial_widths_other_than_the_published_ones(eta_r, hip, tmp_path):
+    """The backward kernel's radial Gaussians come from a recurrence (six exponentials for sixteen shifts) whose factors
+    depend on EtaR, the shift spacing and the cutoff; `fast_kind()` sends parameter sets whose factors could leave fp32 to the
+    generic kernels.  ANI-2x shaped models with other radial widths, against the oracle: two inside the guard, one beyond
+    (reference: the parameters come from the model file, models/lammps_ani.py:130-216 does not fix them)."""
+    from oracle import Oracle
+    m = mf.synthetic_model("ani2x", 2, 11)
+    m.EtaR = eta_r
+    p = str(tmp_path / f"ani2x_eta{eta_r:g}.anim")
+    mf.write_model(p, m)
+    inp = hx.decompose(hx.water_box(900, seed=4), cutoff=5.1, skin=2.0)
+    ani = hip.ANI(p, 0)
+    got = ani.compute(inp, ago=0)
+    _check(got, Oracle(p).compute(inp), inp.nlocal, f"EtaR={eta_r}")
+    ani.close()
+
+
 def test_hip_refuses_cpu(model_cache, hip):
     p = model_cache("tiny", 2, 5)
     with pytest.raises(hip.AniError, match="cpu"):
