@@ -210,6 +210,10 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *       member writing its own dE/dAEV rows, summed afterwards.  One member and fewer than ~16 000 atoms: the chained per-layer
  *       launch is faster and is used.  2 = the fused kernel whatever the size, 3 = the same with a tile's members one after
  *       the other in its workgroup (tests, measurements).  Takes effect at the next call.
+ *   "aev_fused" (default 1): the per-step screening of the candidate lists (neighbour compaction) runs inside the forward AEV
+ *     launch, each wave on the centre it is about to featurise, instead of as a kernel of its own in front of it; 0 = two
+ *     kernels.  Same results; candidate lists longer than 256 entries and AEV shapes off the fast path take the two kernels
+ *     whatever the option says.
  *   "mlp_fused_schedule" (default 1): which workgroup of the fused launch runs which tiles is decided on the host, once per
  *       re-neighbouring, by first-fit-decreasing on the tiles' costs (the smallest makespan that packs them into the CUs);
  *       0 = the workgroups draw tiles from a counter, costliest first.  Takes effect at the next call.

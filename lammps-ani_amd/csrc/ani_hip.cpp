@@ -117,6 +117,7 @@ struct ani_handle {
   bool prune = true;  // ani_set_option("prune_absent_species")
   int mlp_pipeline = 1;   // ani_set_option("mlp_pipeline"): 1 = large systems run all MLP layers as one launch of persistent workgroups
                           // with per-tile dependencies, 2 = at any size (measurement knob), 0 = one launch per layer
+  int aev_fused = 1;         // ani_set_option("aev_fused"): 1 = neighbour compaction inside the forward AEV launch, 0 = its own kernel
   int mlp_fused_sched = 1;   // ani_set_option("mlp_fused_schedule"): 1 = static first-fit schedule of the fused launch, 0 = a counter
   int mlp_fused = 1;   // ani_set_option("mlp_fused"): 1 = networks of three hidden layers run as one launch, a 128-row tile per
                        // workgroup with the activations in registers (ani_kernels_mlpf.hip); 0 = the per-layer kernels
@@ -990,6 +991,14 @@ AevArgs step_aev_args(ani_handle* h, const StepCtx& c, int rows) {
 }
 
 int step_compact_forward(ani_handle* h, const AevArgs& a, hipStream_t st) {
+  if (h->aev_fused) {
+    TraceRange tr("ani: neighbour compaction + AEV forward");
+    if (h->evt) HIP_TRY(h, hipEventRecord(h->evt[5], st));   // the compaction phase is inside the forward launch
+    if (launch_aev_forward_fused(h->ap_run, a, h->max_numneigh, st)) {
+      if (h->evt) HIP_TRY(h, hipEventRecord(h->evt[1], st));
+      return ANI_OK;
+    }
+  }
   {
     TraceRange tr("ani: neighbour compaction");
     launch_nbr_compact(h->ap_run, a, h->max_numneigh, st);
@@ -1176,6 +1185,7 @@ int ani_create(const char* model_file, int local_rank, int use_num_models, int u
   if (const char* tf = getenv("LAMMPS_ANI_ALLOW_TF32")) {
     if (tf[0] && strcmp(tf, "0") != 0) h->mlp_arith = MLP_F16X2;
   }
+  if (const char* e = getenv("ANI_AEV_FUSED")) h->aev_fused = atoi(e) != 0;   // experiment knob: the default of option "aev_fused"
   int rc = upload_model(h);
   if (rc != ANI_OK) { g_create_error = h->err; ani_destroy(h); return rc; }
   // banner, same fields as src/ani_csrc/ani.cpp:88-92
@@ -1593,6 +1603,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   if (strcmp(name, "mlp_fused") == 0) {
     if (value < 0 || value > 3) { h->err = "mlp_fused must be 0, 1, 2 or 3"; return ANI_ERR_ARG; }
     h->mlp_fused = value;
+    return ANI_OK;
+  }
+  if (strcmp(name, "aev_fused") == 0) {
+    h->aev_fused = value != 0;
     return ANI_OK;
   }
   if (strcmp(name, "mlp_fused_schedule") == 0) {

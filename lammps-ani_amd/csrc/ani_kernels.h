@@ -206,6 +206,8 @@ int aev_compact_stride(const AevParams& p, int max_numneigh);
 void launch_nbr_compact(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st);
 // max_numneigh (known at rebuild) sizes the per-centre LDS neighbour lists of the fast path
 void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st);
+// compaction + forward as ONE launch (fast path, candidate lists of at most 256 entries); false: not applicable
+bool launch_aev_forward_fused(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st);
 // optional pairwise repulsion folded into the radial stage of the fast backward kernel (tables indexed by the compact
 // species of the run, like the AEV layout); `on` = 0: none.  Returns true if the kernel that ran applied it (the fast
 // path); false: the caller adds it with launch_repulsion.

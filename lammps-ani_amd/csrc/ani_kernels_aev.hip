@@ -44,6 +44,9 @@ constexpr int kWavesB = 4;   // backward fast path
 #ifndef ANI_FWD_MINW
 #define ANI_FWD_MINW 4
 #endif
+#ifndef ANI_FUSED_MINW
+#define ANI_FUSED_MINW 4
+#endif
 constexpr int kAevMax = 1024;   // LDS floats reserved for one AEV row (ANI-2x: 1008)
 constexpr int kMaxBuckets = 36; // species pairs on the fast path (S <= 8)
 
@@ -768,15 +771,25 @@ __device__ __forceinline__ void build_row_descriptors(FastLds& L, int nbk, int n
   }
 }
 
+// forward_compute: the AEV row of one centre from the wave's LDS lists (radial list grouped by species, angular list, group
+// starts) -- filled from the compact list by forward_centre, or straight from the candidate list by the fused kernel
+template <int NA, int NZ>
+__device__ __forceinline__ void forward_compute(const AevParams& p, const AevArgs& a, FastLds& L, int row, int lane BWD_STAMP_PARAMS);
+
 template <int NA, int NZ, int NCH>
 __device__ __forceinline__ void forward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
                                                const Loaded<NCH, false, 1>& pf, int lane BWD_STAMP_PARAMS) {
-  constexpr int NR = 16, Q = 64 / NA;
   for (int e = lane; e < (p.aev_stride >> 2); e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
   int nrad, nang;
   unpack_lists<NCH>(p, a, row, h, pf, lane, L, nrad, nang);
   wave_sync();
   BWD_STAMP(2);   // unpack
+  forward_compute<NA, NZ>(p, a, L, row, lane BWD_STAMP_ARGS);
+}
+
+template <int NA, int NZ>
+__device__ __forceinline__ void forward_compute(const AevParams& p, const AevArgs& a, FastLds& L, int row, int lane BWD_STAMP_PARAMS) {
+  constexpr int NR = 16, Q = 64 / NA;
 
   // ---- radial: per species group, lanes = (slot q, shift k) ----
 #ifndef ABLF_NO_RAD
@@ -979,6 +992,136 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FWD_MINW) void aev_forward_fast(Ae
 #else
   ANI_PERSISTENT_LOOP(kWaves, NCH, false, 1, (forward_centre<NA, NZ, NCH>(p, a, L, row, hc, cur, lane)))
 #endif
+}
+
+// ---- the forward pass with the per-step compaction inside ("aev_fused") ----------------------------------------------------
+// nbr_compact_kernel is bound by latency (list -> positions -> stores, little arithmetic: 0.09 ms at 100 000 centres at a third
+// of the memory system's rate), aev_forward_fast by vector issue; run one after the other, each leaves the other's resource
+// idle.  Here the wave that computes a centre's AEV row screens its candidate list itself: the gathers of the centre in hand
+// are covered by the arithmetic of the five other waves of the SIMD, the descriptor and the candidate indices of the wave's
+// NEXT centre travel during the arithmetic of this one (three registers), the LDS lists are filled straight from the
+// screened candidates (no compact list read back, no unpack from it), and the compact list and its header are still
+// written -- the backward kernel starts from them.  Candidate lists longer than 64 NCHC entries, or AEV shapes off the fast
+// path, take the two kernels.
+template <int NA, int NZ, int NCHC>
+__global__ __launch_bounds__(64 * kWaves, ANI_FUSED_MINW) void aev_forward_fused(AevParams p, AevArgs a, int cap, int rowf) {
+  extern __shared__ float4 smem4[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, false, rowf, p.S), cap, false, rowf);
+  const int nw = gridDim.x * kWaves;
+  int k = blockIdx.x * kWaves + wave;
+  if (k >= a.kcount) return;
+  const int cap2 = a.cl_stride - kMaxAng;   // room of the radial-only stream
+  const float half_inv_Rcr = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;  // r/(2 Rcr) revolutions
+  const float half_inv_Rca = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
+  int4 info = load_info(a, k);
+  int jj[NCHC];
+  load_j(a, info, lane, jj);
+  while (k < a.kcount) {
+    const int4 info1 = load_info(a, k + nw);   // in flight beside the gathers
+    float4 xi, xx[NCHC];
+    gather_x(a, info, jj, xi, xx);
+    int jj1[NCHC];
+    load_j(a, info1, lane, jj1);               // needs info1 only: the gathers stay in flight
+    const int4 inf = uniform4(info);
+    const int row = inf.w, i = inf.x, n = inf.x < 0 ? 0 : inf.z;
+    for (int e = lane; e < (p.aev_stride >> 2); e += 64) reinterpret_cast<float4*>(L.row)[e] = make_float4(0, 0, 0, 0);
+    int4* hdr = a.cl_hdr + 2 * (size_t)row;
+    float4* oxyz = a.cl_xyz + (size_t)row * a.cl_stride;
+    int* oj = a.cl_j + (size_t)row * a.cl_stride;
+    // ---- screen (as nbr_compact_kernel): two append-only streams, per-species counts in lane s ----
+    int nA = 0, nR = 0, ca = 0, c2 = 0;
+    float4 dd[NCHC];
+    int pos[NCHC];   // slot in the row's compact list: [0, kMaxAng) angular stream, kMaxAng + .. radial-only stream, -1 screened out
+#pragma unroll
+    for (int c = 0; c < NCHC; c++) {
+      pos[c] = -1;
+      dd[c] = make_float4(0.f, 0.f, 0.f, 1.f);
+      if (64 * c < n) {   // wave-uniform
+        const bool valid = 64 * c + lane < n;
+        const float4 xj = xx[c];
+        float4 d;
+        d.x = xj.x - xi.x; d.y = xj.y - xi.y; d.z = xj.z - xi.z;
+        d.w = __builtin_amdgcn_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+        const int sp = __float_as_int(xj.w);
+        const bool in_a = valid && d.w <= p.Rca;
+        const bool in_2 = valid && !in_a && (p.compat || d.w <= p.Rcr);
+        const unsigned long long mA = __ballot(in_a), m2 = __ballot(in_2);
+        const int pA = nA + lanes_below(mA), p2 = nR + lanes_below(m2);
+        for (int s = 0; s < p.S; s++) {
+          const int k1 = __popcll(__ballot(in_a && sp == s)), k2 = __popcll(__ballot(in_2 && sp == s));
+          if (lane == s) { ca += k1; c2 += k2; }
+        }
+        nA += __popcll(mA);
+        nR += __popcll(m2);
+        dd[c] = d;
+        pos[c] = (in_a && pA < kMaxAng) ? pA : ((in_2 && p2 < cap2) ? kMaxAng + p2 : -1);
+      }
+    }
+    // the next centre's candidate indices are in registers before this centre's stores enter the (in-order) memory queue
+#pragma unroll
+    for (int c = 0; c < NCHC; c++) touch(jj1[c]);
+    const bool over = nA > kMaxAng || nR > cap2 || nA + nR > cap;   // never a silent truncation: row skipped, flag raised
+#pragma unroll
+    for (int c = 0; c < NCHC; c++)
+      if (pos[c] >= 0) { oxyz[pos[c]] = dd[c]; oj[pos[c]] = jj[c]; }
+    if (lane < 8) {
+      reinterpret_cast<unsigned char*>(hdr)[8 + lane] = (unsigned char)ca;
+      reinterpret_cast<unsigned short*>(hdr)[8 + lane] = (unsigned short)c2;
+    }
+    if (lane == 0) {
+      reinterpret_cast<int*>(hdr)[0] = (over || inf.x < 0) ? -1 : i;
+      reinterpret_cast<int*>(hdr)[1] = (nA + nR) | (nA << 16) | (__float_as_int(xi.w) << 24);
+      if (over) atomicOr(a.err_flag, 1);
+    }
+    if (!over && inf.x >= 0) {
+      // ---- LDS lists straight from the screened candidates (the arithmetic of unpack_lists) ----
+      Groups g;
+      g.as[0] = g.r2[0] = g.rs[0] = 0;
+#pragma unroll
+      for (int s = 0; s < 8; s++) {
+        const int cak = __builtin_amdgcn_readlane(ca, s), c2k = __builtin_amdgcn_readlane(c2, s);
+        g.as[s + 1] = g.as[s] + cak;
+        g.r2[s + 1] = g.r2[s] + c2k;
+        g.rs[s + 1] = g.rs[s] + cak + c2k;
+      }
+      store_starts(p, g, nA + nR, nA, lane, L);
+#pragma unroll
+      for (int c = 0; c < NCHC; c++) {
+        if (pos[c] >= 0) {
+          const bool ang = pos[c] < kMaxAng;
+          const int w = ang ? pos[c] : pos[c] - kMaxAng;
+          int pr = w;   // species 0: the radial-only entries follow its as[1] angular ones
+          int lead = g.as[1];
+#pragma unroll
+          for (int s = 1; s < 8; s++)
+            if (s < p.S) {
+              const int st = ang ? g.as[s] : g.r2[s];
+              if (w >= st) { pr = g.rs[s] + (w - st); lead = g.as[s + 1] - g.as[s]; }
+            }
+          if (!ang) pr += lead;
+          const float4 v = dd[c];
+          L.rr[pr] = v.w;
+          L.rfc[pr] = 0.5f * fcos_rev(v.w * half_inv_Rcr) + 0.5f;
+          if (ang) {
+            L.ad[w] = v;
+            L.afc[w] = 0.5f * fcos_rev(v.w * half_inv_Rca) + 0.5f;
+          }
+        }
+      }
+      wave_sync();
+#ifdef ABLB_STAMPS
+      unsigned long long stamp_prev = 0, stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      forward_compute<NA, NZ>(p, a, L, row, lane, stamp_prev, stamp_acc);
+#else
+      forward_compute<NA, NZ>(p, a, L, row, lane);
+#endif
+    }
+    info = info1;
+#pragma unroll
+    for (int c = 0; c < NCHC; c++) jj[c] = jj1[c];
+    k += nw;
+  }
 }
 
 // coalesced force scatter of `cnt` neighbours whose gradients sit in LDS as g[3*q + k] with atom indices jx[q]:
@@ -1883,6 +2026,26 @@ void launch_aev_forward(const AevParams& p, const AevArgs& a, int max_numneigh, 
   } else {
     hipLaunchKernelGGL(aev_forward_generic, grid, block, 0, st, p, a);
   }
+}
+
+// compaction + forward in one launch; false: not applicable (the caller launches the two kernels)
+bool launch_aev_forward_fused(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st) {
+  if (a.nrows <= 0 || a.kcount <= 0 || !aev_fast_path(p, max_numneigh) || max_numneigh > 256) return false;
+  const int cap = radial_cap(p, max_numneigh);
+  const int rowf = (p.aev_stride + 63) / 64 * 64;
+  const size_t lds = (size_t)fast_wave_floats_row(cap, false, rowf, p.S) * 4 * kWaves;
+  const bool k1 = fast_kind(p) == 1;
+  const int nch = max_numneigh <= 128 ? 2 : (max_numneigh <= 192 ? 3 : 4);
+  if (k1) {
+    if (nch == 2) launch_fast(aev_forward_fused<8, 4, 2>, p, a, kWaves, lds, cap, rowf, st);
+    else if (nch == 3) launch_fast(aev_forward_fused<8, 4, 3>, p, a, kWaves, lds, cap, rowf, st);
+    else launch_fast(aev_forward_fused<8, 4, 4>, p, a, kWaves, lds, cap, rowf, st);
+  } else {
+    if (nch == 2) launch_fast(aev_forward_fused<4, 8, 2>, p, a, kWaves, lds, cap, rowf, st);
+    else if (nch == 3) launch_fast(aev_forward_fused<4, 8, 3>, p, a, kWaves, lds, cap, rowf, st);
+    else launch_fast(aev_forward_fused<4, 8, 4>, p, a, kWaves, lds, cap, rowf, st);
+  }
+  return true;
 }
 
 bool launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh, hipStream_t st, const RepTab* rep) {

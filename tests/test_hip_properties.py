@@ -256,6 +256,29 @@ def test_chained_mlp_launch_equals_per_layer_launches(model_cache, hip):
         ani.close()
 
 
+def test_compaction_inside_the_forward_launch_equals_the_two_kernels(model_cache, hip):
+    """Option aev_fused (default 1): the wave that featurises a centre screens its candidate list itself; 0 = the compaction
+    kernel in front of the forward kernel.  Both fill the same LDS lists in the same order, so the AEV rows must be equal BIT BY
+    BIT and the compact lists the backward kernel starts from too (forces differ by the order of the fp32 force atomics only).
+    Water (pruned AEV), a 7-species box, an ANI-1x shaped model (the other kernel instantiation) and the unscreened radial
+    list (use_cuaev = False: every candidate stays, three chunks per centre)."""
+    cases = [("ani2x", hx.decompose(hx.water_box(6000, seed=3)), True), ("ani2x", hx.decompose(hx.random_box(1200, 7, 26.0, seed=6)), True),
+             ("ani1x", hx.decompose(hx.random_box(900, 4, 24.0, seed=8), cutoff=5.2), True), ("ani2x", hx.decompose(hx.water_box(3000, seed=5)), False)]
+    for kind, inp, cuaev in cases:
+        p = model_cache(kind, 2, 77)
+        ani = hip.ANI(p, 0, use_cuaev=cuaev)
+        out, rows = [], []
+        for fused in (1, 0):
+            ani.set_option("aev_fused", fused)
+            out.append(ani.compute(inp, ago=0))
+            v = ani.debug_view()
+            rows.append(ani.debug_read(v.d_aev, (v.nrows, v.aev_stride), np.float32))
+        assert np.array_equal(rows[0], rows[1])
+        assert abs(out[0]["energy"] - out[1]["energy"]) < 1e-5   # the same rows through the same MLP: the order of the energy sum only
+        assert np.abs(out[0]["force"] - out[1]["force"]).max() < 0.02 * F_TOL
+        ani.close()
+
+
 @pytest.mark.parametrize("natoms", [3000, 24000, 60000])
 def test_mlp_pipeline_equals_per_layer_launches_on_changing_inputs(natoms, model_cache, hip):
     """Large single-member systems run all MLP layers as ONE launch of persistent workgroups: tile t of layer l waits for a
