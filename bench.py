@@ -465,7 +465,8 @@ def main():
         t_f = t_fwd + t_cmp
         fwd_roof = dict(bound="hbm", achieved=bf / (t_f * 1e-3) / 1e9 if t_f > 0 else None, peak=PEAK_HBM_GBS, unit="GB/s",
                         traffic=(hbm_traffic("ani::aev_forward") or 0) + (hbm_traffic("ani::nbr_compact") or 0) if pmc else None,
-                        kernel="nbr_compact_kernel + aev_forward_fast", ms_per_launch=t_f, ms_compact=t_cmp, ms_forward=t_fwd,
+                        kernel=("aev_forward_fused (neighbour compaction + AEV forward in one launch)" if t_cmp < 0.25 * t_fwd and t_cmp < 0.02
+                                else "nbr_compact_kernel + aev_forward_fast"), ms_per_launch=t_f, ms_compact=t_cmp, ms_forward=t_fwd,
                         bytes_per_launch=bf, valu_frac=valu("ani::aev_forward", t_fwd), valu_frac_4cyc=valu4("ani::aev_forward", t_fwd))
         fwd_roof["frac"] = fwd_roof["achieved"] / PEAK_HBM_GBS if fwd_roof["achieved"] else None
         # The MLP against the three things that can bound it.  The library default evaluates an fp32 product EXACTLY as six
