@@ -160,6 +160,7 @@ struct ani_handle {
   int sticky_flags = 0;   // every bit the device error word has ever shown the host (bit 1: LDS capacity, bit 2: MLP wait timeout)
   int max_numneigh = 0;
   DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
+  DevBuf<int> row_ctr;   // {ticket, waves done} pairs of the fused forward launch, one pair per row range (AevArgs::row_counter)
   DevBuf<float4> xyzs, cl_xyz;
   DevBuf<int4> row_info, cl_hdr;
   DevBuf<int> cl_j;
@@ -947,6 +948,7 @@ int step_prologue(ani_handle* h, const StepCtx& c, bool timed, hipStream_t st) {
   HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 4));  // one float4 per atom
   HIP_TRY(h, h->virial_acc.reserve(9 * kVirialSlots));
   HIP_TRY(h, h->err_flag.reserve(1, true));
+  HIP_TRY(h, h->row_ctr.reserve((size_t)3 * kTicketGroups * kTicketStride, true));
   h->evt = nullptr;
   if (timed && h->timing) {
     if (h->evt_used + 6 > h->evt_pool.size()) {
@@ -985,6 +987,7 @@ AevArgs step_aev_args(ani_handle* h, const StepCtx& c, int rows) {
   a.err_flag = h->err_flag.p;
   a.cl_hdr = h->cl_hdr.p; a.cl_xyz = h->cl_xyz.p; a.cl_j = h->cl_j.p; a.cl_stride = h->cl_stride;
   a.row_list = nullptr; a.k0 = 0; a.kcount = h->nrows;
+  a.row_counter = h->row_ctr.p ? h->row_ctr.p + rows * kTicketGroups * kTicketStride : nullptr;
   if (rows == 1) { a.row_list = h->row_list.p; a.k0 = 0; a.kcount = h->n_boundary; }
   if (rows == 2) { a.row_list = h->row_list.p; a.k0 = h->n_boundary; a.kcount = h->nrows - h->n_boundary; }
   return a;
@@ -1226,7 +1229,7 @@ void ani_destroy(ani_handle* h) {
     if (n.b_out64) (void)hipFree(n.b_out64);
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
-  h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release();
+  h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release(); h->row_ctr.release();
   h->xyzs.release(); h->cl_xyz.release(); h->cl_hdr.release(); h->cl_j.release(); h->row_info.release(); h->row_flag.release(); h->row_list.release(); h->row_count.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->origin.release();
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();

@@ -175,6 +175,11 @@ size_t prepare_scratch_ints(int nlocal);   // size of PrepOut::row_of_centre (ro
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
                     const PrepOut& o, hipStream_t st);
 
+#ifndef ANI_TK_GROUPS
+#define ANI_TK_GROUPS 64
+#endif
+constexpr int kTicketGroups = ANI_TK_GROUPS;   // row-ticket counters of a fused forward launch (AevArgs::row_counter) ...
+constexpr int kTicketStride = 64;   // ... one per 256 bytes: {next ticket, waves done, -...}
 struct AevArgs {
   const float4* xyzs;
   const int* ilist;
@@ -199,6 +204,10 @@ struct AevArgs {
   // (every row: k0 = 0, kcount = nrows).  The generic kernels always take every row.
   const int* row_list;
   int k0, kcount;
+  // forward launch with the compaction inside: kTicketGroups x {next ticket, waves done} at a stride of kTicketStride ints -- its
+  // waves draw their rows from their group's counter instead of a fixed stride (a group's last wave out resets the pair for the
+  // next launch); NULL: fixed stride
+  int* row_counter;
 };
 // entries per row the compact lists need (0: the model shape takes the generic kernels, which keep no lists)
 int aev_compact_stride(const AevParams& p, int max_numneigh);

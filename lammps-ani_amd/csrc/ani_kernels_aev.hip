@@ -954,16 +954,60 @@ __device__ __forceinline__ void forward_compute(const AevParams& p, const AevArg
 // them one centre ahead (two register stages used alternately, secured before the centre's stores and atomics entered
 // the in-order vmcnt queue) was built and measured: forward unchanged, backward 4 % SLOWER -- the second stage costs
 // 22 registers that the pair loop uses better.
-#define ANI_PERSISTENT_LOOP(KW, NCH, BWD, GR, CENTRE)                                                      \
+// Which rows a wave takes: by ticket when the launch has counters (AevArgs::row_counter) -- centres cost differently, and with a
+// fixed stride a kernel ends with its unluckiest wave (forward pass with the compaction inside: 0.252 -> 0.224 ms) -- else a
+// fixed stride.  The workgroups form kTicketGroups groups (blockIdx mod groups), each with a contiguous share of the rows and
+// a counter of its own (ONE counter would serialise 100 000 same-address atomics: measured 1.3 ms).  A wave holds the tickets
+// of its current and its next centre and has two more on their way: the one drawn a centre ago is taken behind the centre's
+// first wait for loaded data, at no cost (the memory queue is in order).  A group's last wave out leaves the counters at zero for the next launch on the stream.
+#define ANI_TICKETS_BEGIN(KW)                                                                              \
   const int nw = gridDim.x * KW;                                                                          \
-  for (int k = blockIdx.x * KW + wave; k < a.kcount; k += nw) {                                           \
-    const int row = a.row_list ? __builtin_amdgcn_readfirstlane(a.row_list[a.k0 + k]) : a.k0 + k;         \
-    const hdr_t hc = load_header(a, row);                                                                 \
-    if (hc[0] < 0) continue;                                                                              \
-    Loaded<NCH, BWD, GR> cur;                                                                             \
-    load_lists(p, a, row, hdr_nrad(hc), hdr_nang(hc), lane, cur);                                         \
-    CENTRE;                                                                                               \
+  const int tk_ngrp = min((int)gridDim.x, kTicketGroups), tk_grp = blockIdx.x % tk_ngrp;                  \
+  const int tk_share = (a.kcount + tk_ngrp - 1) / tk_ngrp, tk_base = tk_grp * tk_share;                   \
+  int* const tk_ctr = a.row_counter ? a.row_counter + kTicketStride * tk_grp : nullptr;                   \
+  const int kend = tk_ctr ? min(a.kcount, tk_base + tk_share) : a.kcount;                                 \
+  int k = blockIdx.x * KW + wave, k1 = k + nw, tk_pending = 0;                                            \
+  if (tk_ctr) {                                                                                           \
+    int t0 = 0, t1 = 0;                                                                                   \
+    if (lane == 0) { t0 = atomicAdd(tk_ctr, 1); t1 = atomicAdd(tk_ctr, 1); tk_pending = atomicAdd(tk_ctr, 1); } \
+    k = tk_base + __builtin_amdgcn_readfirstlane(t0);                                                     \
+    k1 = tk_base + __builtin_amdgcn_readfirstlane(t1);                                                    \
   }
+/* at the top of a centre: the ticket three centres ahead leaves ... */
+#define ANI_TICKET_DRAW(tn)                                                                                \
+  int tn = 0;                                                                                             \
+  if (tk_ctr && lane == 0) tn = atomicAdd(tk_ctr, 1);
+/* ... and behind the centre's first wait for loaded data (which, the memory queue being in order, is also a wait for everything
+   the wave issued before): the ticket drawn a centre ago is taken into a scalar register */
+#define ANI_TICKET_TAKE(k2)                                                                                \
+  touch(tk_pending);                                                                                      \
+  const int k2 = tk_base + __builtin_amdgcn_readfirstlane(tk_pending);
+#define ANI_TICKET_NEXT(tn, k2)                                                                            \
+  k = k1;                                                                                                 \
+  k1 = tk_ctr ? k2 : k1 + nw;                                                                             \
+  tk_pending = tn;
+#define ANI_TICKETS_END(KW)                                                                                \
+  if (tk_ctr && lane == 0 && atomicAdd(tk_ctr + 1, 1) == ((int)gridDim.x - tk_grp + tk_ngrp - 1) / tk_ngrp * KW - 1) { \
+    __atomic_store_n(tk_ctr, 0, __ATOMIC_RELAXED);                                                        \
+    __atomic_store_n(tk_ctr + 1, 0, __ATOMIC_RELAXED);                                                    \
+  }
+#define ANI_PERSISTENT_LOOP(KW, NCH, BWD, GR, CENTRE)                                                      \
+  ANI_TICKETS_BEGIN(KW)                                                                                   \
+  while (k < ((tk_ctr && BWD) ? tk_base + tk_share : kend)) {                                             \
+    ANI_TICKET_DRAW(tk_tn)                                                                                \
+    const int kk = (tk_ctr && BWD) ? (k - tk_base) * tk_ngrp + tk_grp : k;   /* backward: a group's rows interleaved with the others' */ \
+    const int kc = kk < a.kcount ? kk : a.kcount - 1;                                                     \
+    const int row = a.row_list ? __builtin_amdgcn_readfirstlane(a.row_list[a.k0 + kc]) : a.k0 + kc;       \
+    const hdr_t hc = load_header(a, row);                                                                 \
+    ANI_TICKET_TAKE(tk_k2)                                                                                \
+    if (hc[0] >= 0 && kk < a.kcount) {                                                                    \
+      Loaded<NCH, BWD, GR> cur;                                                                           \
+      load_lists(p, a, row, hdr_nrad(hc), hdr_nang(hc), lane, cur);                                       \
+      CENTRE;                                                                                             \
+    }                                                                                                     \
+    ANI_TICKET_NEXT(tk_tn, tk_k2)                                                                         \
+  }                                                                                                       \
+  ANI_TICKETS_END(KW)
 
 template <int NA, int NZ, int NCH>
 __global__ __launch_bounds__(64 * kWaves, ANI_FWD_MINW) void aev_forward_fast(AevParams p, AevArgs a, int cap, int rowf) {
@@ -1008,17 +1052,16 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FUSED_MINW) void aev_forward_fused
   extern __shared__ float4 smem4[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   FastLds L = carve<NA, NZ>(reinterpret_cast<float*>(smem4) + wave * fast_wave_floats_row(cap, false, rowf, p.S), cap, false, rowf);
-  const int nw = gridDim.x * kWaves;
-  int k = blockIdx.x * kWaves + wave;
-  if (k >= a.kcount) return;
+  ANI_TICKETS_BEGIN(kWaves)   // rows by ticket (see ANI_PERSISTENT_LOOP)
   const int cap2 = a.cl_stride - kMaxAng;   // room of the radial-only stream
   const float half_inv_Rcr = 0.5f * p.pi_over_Rcr * 0.3183098861837907f;  // r/(2 Rcr) revolutions
   const float half_inv_Rca = 0.5f * p.pi_over_Rca * 0.3183098861837907f;
   int4 info = load_info(a, k);
   int jj[NCHC];
   load_j(a, info, lane, jj);
-  while (k < a.kcount) {
-    const int4 info1 = load_info(a, k + nw);   // in flight beside the gathers
+  while (k < kend) {   // a group's rows are contiguous here (interleaved with the other groups' they run no faster or slower)
+    ANI_TICKET_DRAW(tn)
+    const int4 info1 = load_info(a, k1);       // in flight beside the gathers
     float4 xi, xx[NCHC];
     gather_x(a, info, jj, xi, xx);
     int jj1[NCHC];
@@ -1061,6 +1104,7 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FUSED_MINW) void aev_forward_fused
     // the next centre's candidate indices are in registers before this centre's stores enter the (in-order) memory queue
 #pragma unroll
     for (int c = 0; c < NCHC; c++) touch(jj1[c]);
+    ANI_TICKET_TAKE(k2)
     const bool over = nA > kMaxAng || nR > cap2 || nA + nR > cap;   // never a silent truncation: row skipped, flag raised
 #pragma unroll
     for (int c = 0; c < NCHC; c++)
@@ -1120,8 +1164,9 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FUSED_MINW) void aev_forward_fused
     info = info1;
 #pragma unroll
     for (int c = 0; c < NCHC; c++) jj[c] = jj1[c];
-    k += nw;
+    ANI_TICKET_NEXT(tn, k2)
   }
+  ANI_TICKETS_END(kWaves)
 }
 
 // coalesced force scatter of `cnt` neighbours whose gradients sit in LDS as g[3*q + k] with atom indices jx[q]:
