@@ -948,7 +948,7 @@ int step_prologue(ani_handle* h, const StepCtx& c, bool timed, hipStream_t st) {
   HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 4));  // one float4 per atom
   HIP_TRY(h, h->virial_acc.reserve(9 * kVirialSlots));
   HIP_TRY(h, h->err_flag.reserve(1, true));
-  HIP_TRY(h, h->row_ctr.reserve((size_t)3 * kTicketGroups * kTicketStride, true));
+  HIP_TRY(h, h->row_ctr.reserve((size_t)3 * kTicketMaxGroups * kTicketStride, true));
   h->evt = nullptr;
   if (timed && h->timing) {
     if (h->evt_used + 6 > h->evt_pool.size()) {
@@ -987,9 +987,13 @@ AevArgs step_aev_args(ani_handle* h, const StepCtx& c, int rows) {
   a.err_flag = h->err_flag.p;
   a.cl_hdr = h->cl_hdr.p; a.cl_xyz = h->cl_xyz.p; a.cl_j = h->cl_j.p; a.cl_stride = h->cl_stride;
   a.row_list = nullptr; a.k0 = 0; a.kcount = h->nrows;
-  a.row_counter = h->row_ctr.p ? h->row_ctr.p + rows * kTicketGroups * kTicketStride : nullptr;
+  a.row_counter = h->row_ctr.p ? h->row_ctr.p + rows * kTicketMaxGroups * kTicketStride : nullptr;
   if (rows == 1) { a.row_list = h->row_list.p; a.k0 = 0; a.kcount = h->n_boundary; }
   if (rows == 2) { a.row_list = h->row_list.p; a.k0 = h->n_boundary; a.kcount = h->nrows - h->n_boundary; }
+  // rows by ticket pay from a few rows per wave on (the ~5000 resident waves of a launch each draw three tickets before their
+  // first centre): below that the fixed stride is as good and starts at once.  ANI_AEV_TICKETS_MIN: experiment knob.
+  static const int tickets_min = [] { const char* e = getenv("ANI_AEV_TICKETS_MIN"); return e ? atoi(e) : 40000; }();
+  if (a.kcount < tickets_min) a.row_counter = nullptr;
   return a;
 }
 

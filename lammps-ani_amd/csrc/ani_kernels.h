@@ -179,6 +179,8 @@ void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numne
 #define ANI_TK_GROUPS 64
 #endif
 constexpr int kTicketGroups = ANI_TK_GROUPS;   // row-ticket counters of a fused forward launch (AevArgs::row_counter) ...
+constexpr int kTicketMaxGroups = 256;            // what the counter block of a row range has room for
+static_assert(kTicketGroups <= kTicketMaxGroups, "ANI_TK_GROUPS");
 constexpr int kTicketStride = 64;   // ... one per 256 bytes: {next ticket, waves done, -...}
 struct AevArgs {
   const float4* xyzs;
