@@ -214,6 +214,8 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *     launch, each wave on the centre it is about to featurise, instead of as a kernel of its own in front of it; 0 = two
  *     kernels.  Same results; candidate lists longer than 256 entries and AEV shapes off the fast path take the two kernels
  *     whatever the option says.
+ *   "aev_tickets_min" (default 40000): AEV launches over at least this many rows hand their rows to the waves by ticket (64 groups
+ *     of workgroups, a counter each) instead of at a fixed stride; smaller launches keep the stride.  Same results.
  *   "mlp_fused_schedule" (default 1): which workgroup of the fused launch runs which tiles is decided on the host, once per
  *       re-neighbouring, by first-fit-decreasing on the tiles' costs (the smallest makespan that packs them into the CUs);
  *       0 = the workgroups draw tiles from a counter, costliest first.  Takes effect at the next call.

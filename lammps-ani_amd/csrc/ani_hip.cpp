@@ -118,6 +118,7 @@ struct ani_handle {
   int mlp_pipeline = 1;   // ani_set_option("mlp_pipeline"): 1 = large systems run all MLP layers as one launch of persistent workgroups
                           // with per-tile dependencies, 2 = at any size (measurement knob), 0 = one launch per layer
   int aev_fused = 1;         // ani_set_option("aev_fused"): 1 = neighbour compaction inside the forward AEV launch, 0 = its own kernel
+  int aev_tickets_min = 40000;   // ani_set_option("aev_tickets_min"): launches of fewer rows keep the fixed stride
   int mlp_fused_sched = 1;   // ani_set_option("mlp_fused_schedule"): 1 = static first-fit schedule of the fused launch, 0 = a counter
   int mlp_fused = 1;   // ani_set_option("mlp_fused"): 1 = networks of three hidden layers run as one launch, a 128-row tile per
                        // workgroup with the activations in registers (ani_kernels_mlpf.hip); 0 = the per-layer kernels
@@ -991,9 +992,8 @@ AevArgs step_aev_args(ani_handle* h, const StepCtx& c, int rows) {
   if (rows == 1) { a.row_list = h->row_list.p; a.k0 = 0; a.kcount = h->n_boundary; }
   if (rows == 2) { a.row_list = h->row_list.p; a.k0 = h->n_boundary; a.kcount = h->nrows - h->n_boundary; }
   // rows by ticket pay from a few rows per wave on (the ~5000 resident waves of a launch each draw three tickets before their
-  // first centre): below that the fixed stride is as good and starts at once.  ANI_AEV_TICKETS_MIN: experiment knob.
-  static const int tickets_min = [] { const char* e = getenv("ANI_AEV_TICKETS_MIN"); return e ? atoi(e) : 40000; }();
-  if (a.kcount < tickets_min) a.row_counter = nullptr;
+  // first centre): below that the fixed stride is as good and starts at once (option "aev_tickets_min")
+  if (a.kcount < h->aev_tickets_min) a.row_counter = nullptr;
   return a;
 }
 
@@ -1192,7 +1192,8 @@ int ani_create(const char* model_file, int local_rank, int use_num_models, int u
   if (const char* tf = getenv("LAMMPS_ANI_ALLOW_TF32")) {
     if (tf[0] && strcmp(tf, "0") != 0) h->mlp_arith = MLP_F16X2;
   }
-  if (const char* e = getenv("ANI_AEV_FUSED")) h->aev_fused = atoi(e) != 0;   // experiment knob: the default of option "aev_fused"
+  if (const char* e = getenv("ANI_AEV_FUSED")) h->aev_fused = atoi(e) != 0;   // experiment knobs: the defaults of the options
+  if (const char* e = getenv("ANI_AEV_TICKETS_MIN")) h->aev_tickets_min = atoi(e);
   int rc = upload_model(h);
   if (rc != ANI_OK) { g_create_error = h->err; ani_destroy(h); return rc; }
   // banner, same fields as src/ani_csrc/ani.cpp:88-92
@@ -1610,6 +1611,11 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   if (strcmp(name, "mlp_fused") == 0) {
     if (value < 0 || value > 3) { h->err = "mlp_fused must be 0, 1, 2 or 3"; return ANI_ERR_ARG; }
     h->mlp_fused = value;
+    return ANI_OK;
+  }
+  if (strcmp(name, "aev_tickets_min") == 0) {
+    if (value < 0) { h->err = "aev_tickets_min must be >= 0"; return ANI_ERR_ARG; }
+    h->aev_tickets_min = value;
     return ANI_OK;
   }
   if (strcmp(name, "aev_fused") == 0) {

@@ -256,6 +256,31 @@ def test_chained_mlp_launch_equals_per_layer_launches(model_cache, hip):
         ani.close()
 
 
+def test_rows_by_ticket_equal_rows_by_stride(model_cache, hip):
+    """Option aev_tickets_min: large launches hand the AEV rows to the waves by ticket (contiguous blocks per group of workgroups
+    in the forward launch, the groups' rows interleaved in the backward launch), small ones at a fixed stride.  Forced on for
+    systems far below the default threshold -- fewer rows than ticket groups, row counts that no group count divides, both
+    forward kernels -- every row must be computed exactly once: AEV rows equal bit by bit, forces to the order of the atomics."""
+    cases = [("ani2x", hx.decompose(hx.water_box(30, seed=2)), 1), ("ani2x", hx.decompose(hx.water_box(1001 * 3, seed=3)), 1),
+             ("ani2x", hx.decompose(hx.random_box(1237, 7, 26.0, seed=6)), 1), ("ani2x", hx.decompose(hx.water_box(6000, seed=5)), 0)]
+    for kind, inp, fused in cases:
+        p = model_cache(kind, 2, 78)
+        ani = hip.ANI(p, 0)
+        ani.set_option("aev_fused", fused)
+        out, rows = [], []
+        for tmin in (0, 1 << 30):
+            ani.set_option("aev_tickets_min", tmin)
+            for _ in range(2):   # twice: the counters must be back at zero after a launch
+                o = ani.compute(inp, ago=0)
+            out.append(o)
+            v = ani.debug_view()
+            rows.append(ani.debug_read(v.d_aev, (v.nrows, v.aev_stride), np.float32))
+        assert np.array_equal(rows[0], rows[1])
+        assert abs(out[0]["energy"] - out[1]["energy"]) < 1e-5
+        assert np.abs(out[0]["force"] - out[1]["force"]).max() < 0.02 * F_TOL
+        ani.close()
+
+
 def test_compaction_inside_the_forward_launch_equals_the_two_kernels(model_cache, hip):
     """Option aev_fused (default 1): the wave that featurises a centre screens its candidate list itself; 0 = the compaction
     kernel in front of the forward kernel.  Both fill the same LDS lists in the same order, so the AEV rows must be equal BIT BY
