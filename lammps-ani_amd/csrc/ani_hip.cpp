@@ -945,6 +945,10 @@ struct StepCtx {
 };
 
 int step_prologue(ani_handle* h, const StepCtx& c, bool timed, hipStream_t st) {
+  if (h->ntotal >= (1 << 28)) {   // the compact lists keep an atom index in 28 bits (AevArgs::cl_j)
+    h->err = "more than 2^28 atoms (owned + ghost) on one rank";
+    return ANI_ERR_ARG;
+  }
   HIP_TRY(h, h->xyzs.reserve(h->ntotal));
   HIP_TRY(h, h->fbuf.reserve((size_t)h->ntotal * 4));  // one float4 per atom
   HIP_TRY(h, h->virial_acc.reserve(9 * kVirialSlots));

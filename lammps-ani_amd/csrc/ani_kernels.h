@@ -200,7 +200,7 @@ struct AevArgs {
   // per-step compact neighbour lists of the fast path (nbr_compact_kernel writes, forward / backward read)
   int4* cl_hdr;      // [2*nrows] {i (-1: skip), nrad | nang<<16 | centre species<<24, 8 x u8 angular counts} | 8 x u16 radial-only counts
   float4* cl_xyz;    // [nrows*cl_stride] {dx, dy, dz, r}: kMaxAng slots for the neighbours inside Rca, then the radial-only ones
-  int* cl_j;         // [nrows*cl_stride] neighbour atom index
+  int* cl_j;         // [nrows*cl_stride] neighbour atom index (low 28 bits) | compact species << 28
   int cl_stride;     // entries reserved per row (kMaxAng + the kernels' radial LDS capacity)
   // the range of rows a fast-path launch walks: row_list[k0 + k], k in [0, kcount); without a list the rows k0 + k
   // (every row: k0 = 0, kcount = nrows).  The generic kernels always take every row.

@@ -285,6 +285,12 @@ __device__ __forceinline__ FastLds carve(float* base, int cap, bool bwd, int row
 // through an index the compiler cannot prove uniform, or it would load + v_readfirstlane it on the spot (draining
 // every gather in flight) -- it is made scalar only when its row is started.
 constexpr int kWavesC = 4;
+// a compact-list entry of cl_j: the neighbour's atom index with its (compact) species in the top four bits, so that the backward
+// kernel's radial stage knows a neighbour's dE/dAEV row without walking the per-species counts (27 scalars that spilled)
+constexpr int kClIndexBits = 28;
+__device__ __forceinline__ int cl_pack(int j, int sp) { return j | (sp << kClIndexBits); }
+__device__ __forceinline__ int cl_index(int e) { return e & ((1 << kClIndexBits) - 1); }
+__device__ __forceinline__ int cl_species(int e) { return (unsigned)e >> kClIndexBits; }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ void touch(int v) { asm volatile("" ::"v"(v)); }
 __device__ __forceinline__ void touch(float v) { asm volatile("" ::"v"(v)); }
@@ -351,10 +357,10 @@ __global__ __launch_bounds__(64 * kWavesC, NCH >= 4 ? 4 : 5) void nbr_compact_ke
     int ca = 0, c2 = 0;    // lane s: entries of species s in either stream
     float4 dd[NCH];
     int pos[NCH];          // output slot of this lane's candidate of chunk c, -1: screened out
-    auto screen = [&](int c, bool valid, const float4& xj, float4& d) -> int {
+    auto screen = [&](int c, bool valid, const float4& xj, float4& d, int& sp) -> int {
       d.x = xj.x - xi.x; d.y = xj.y - xi.y; d.z = xj.z - xi.z;
       d.w = __builtin_amdgcn_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
-      const int sp = __float_as_int(xj.w);
+      sp = __float_as_int(xj.w);
       const bool in_a = valid && d.w <= p.Rca;
       const bool in_2 = valid && !in_a && (p.compat || d.w <= p.Rcr);
       const unsigned long long mA = __ballot(in_a), m2 = __ballot(in_2);
@@ -367,11 +373,13 @@ __global__ __launch_bounds__(64 * kWavesC, NCH >= 4 ? 4 : 5) void nbr_compact_ke
       nR += __popcll(m2);
       return (in_a && pA < kMaxAng) ? pA : ((in_2 && p2 < cap2) ? kMaxAng + p2 : -1);
     };
+    int spv[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
       pos[c] = -1;
+      spv[c] = 0;
       dd[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (64 * c < n) pos[c] = screen(c, 64 * c + lane < n, xx[c], dd[c]);   // wave-uniform test
+      if (64 * c < n) pos[c] = screen(c, 64 * c + lane < n, xx[c], dd[c], spv[c]);   // wave-uniform test
     }
     // everything the later rows need has now to be in registers: the stores below must not be waited for
     touch(xi1); touch(info3);
@@ -379,14 +387,15 @@ __global__ __launch_bounds__(64 * kWavesC, NCH >= 4 ? 4 : 5) void nbr_compact_ke
     for (int c = 0; c < NCH; c++) { touch(xx1[c]); touch(jj2[c]); }
 #pragma unroll
     for (int c = 0; c < NCH; c++)
-      if (pos[c] >= 0) { oxyz[pos[c]] = dd[c]; oj[pos[c]] = jj[c]; }
+      if (pos[c] >= 0) { oxyz[pos[c]] = dd[c]; oj[pos[c]] = cl_pack(jj[c], spv[c]); }
     for (int base0 = 64 * NCH; base0 < n; base0 += 64) {   // more than 64 * NCH list entries: rare, loaded in place
       const int q = base0 + lane;
       const int j = q < n ? a.jlist[beg + q] : i;
       const float4 xj = a.xyzs[j];
       float4 d;
-      const int ps = screen(0, q < n, xj, d);
-      if (ps >= 0) { oxyz[ps] = d; oj[ps] = j; }
+      int sp;
+      const int ps = screen(0, q < n, xj, d, sp);
+      if (ps >= 0) { oxyz[ps] = d; oj[ps] = cl_pack(j, sp); }
     }
     // capacity of the consumers' LDS lists: never a silent truncation -- the row is skipped and the error flag raised
     const bool over = nA > kMaxAng || nR > cap2 || nA + nR > cap;
@@ -1073,12 +1082,15 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FUSED_MINW) void aev_forward_fused
     float4* oxyz = a.cl_xyz + (size_t)row * a.cl_stride;
     int* oj = a.cl_j + (size_t)row * a.cl_stride;
     // ---- screen (as nbr_compact_kernel): two append-only streams, per-species counts in lane s ----
-    int nA = 0, nR = 0, ca = 0, c2 = 0;
+    int nA = 0, nR = 0;
+    int cc = 0;      // lane s: entries of species s in the angular stream (low half) and in the radial-only stream (high half)
+    int spc[NCHC];   // the candidate's (compact) species
     float4 dd[NCHC];
     int pos[NCHC];   // slot in the row's compact list: [0, kMaxAng) angular stream, kMaxAng + .. radial-only stream, -1 screened out
 #pragma unroll
     for (int c = 0; c < NCHC; c++) {
       pos[c] = -1;
+      spc[c] = 0;
       dd[c] = make_float4(0.f, 0.f, 0.f, 1.f);
       if (64 * c < n) {   // wave-uniform
         const bool valid = 64 * c + lane < n;
@@ -1092,11 +1104,13 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FUSED_MINW) void aev_forward_fused
         const unsigned long long mA = __ballot(in_a), m2 = __ballot(in_2);
         const int pA = nA + lanes_below(mA), p2 = nR + lanes_below(m2);
         for (int s = 0; s < p.S; s++) {
-          const int k1 = __popcll(__ballot(in_a && sp == s)), k2 = __popcll(__ballot(in_2 && sp == s));
-          if (lane == s) { ca += k1; c2 += k2; }
+          const unsigned long long ms = __ballot(sp == s);
+          const int k12 = __popcll(mA & ms) | (__popcll(m2 & ms) << 16);
+          if (lane == s) cc += k12;
         }
         nA += __popcll(mA);
         nR += __popcll(m2);
+        spc[c] = sp;
         dd[c] = d;
         pos[c] = (in_a && pA < kMaxAng) ? pA : ((in_2 && p2 < cap2) ? kMaxAng + p2 : -1);
       }
@@ -1108,10 +1122,10 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FUSED_MINW) void aev_forward_fused
     const bool over = nA > kMaxAng || nR > cap2 || nA + nR > cap;   // never a silent truncation: row skipped, flag raised
 #pragma unroll
     for (int c = 0; c < NCHC; c++)
-      if (pos[c] >= 0) { oxyz[pos[c]] = dd[c]; oj[pos[c]] = jj[c]; }
+      if (pos[c] >= 0) { oxyz[pos[c]] = dd[c]; oj[pos[c]] = cl_pack(jj[c], spc[c]); }
     if (lane < 8) {
-      reinterpret_cast<unsigned char*>(hdr)[8 + lane] = (unsigned char)ca;
-      reinterpret_cast<unsigned short*>(hdr)[8 + lane] = (unsigned short)c2;
+      reinterpret_cast<unsigned char*>(hdr)[8 + lane] = (unsigned char)(cc & 0xffff);
+      reinterpret_cast<unsigned short*>(hdr)[8 + lane] = (unsigned short)(cc >> 16);
     }
     if (lane == 0) {
       reinterpret_cast<int*>(hdr)[0] = (over || inf.x < 0) ? -1 : i;
@@ -1119,31 +1133,26 @@ __global__ __launch_bounds__(64 * kWaves, ANI_FUSED_MINW) void aev_forward_fused
       if (over) atomicOr(a.err_flag, 1);
     }
     if (!over && inf.x >= 0) {
-      // ---- LDS lists straight from the screened candidates (the arithmetic of unpack_lists) ----
-      Groups g;
-      g.as[0] = g.r2[0] = g.rs[0] = 0;
-#pragma unroll
-      for (int s = 0; s < 8; s++) {
-        const int cak = __builtin_amdgcn_readlane(ca, s), c2k = __builtin_amdgcn_readlane(c2, s);
-        g.as[s + 1] = g.as[s] + cak;
-        g.r2[s + 1] = g.r2[s] + c2k;
-        g.rs[s + 1] = g.rs[s] + cak + c2k;
-      }
-      store_starts(p, g, nA + nR, nA, lane, L);
+      // ---- LDS lists straight from the screened candidates.  The candidates come sorted by species, so a candidate's place
+      // in the species-grouped radial list is its stream index plus ONE number of its species: an angular entry of species s
+      // sits behind the radial-only entries of the species before it (exclusive prefix of the radial-only counts), a
+      // radial-only entry behind the angular entries up to and including its own species (inclusive prefix of the angular
+      // counts).  The prefixes are a three-level DPP scan over the lanes that hold the counts -- no scalar tables (unpack_lists
+      // walks 27 of them, which here spilled) -- and a candidate fetches its species' pair with one ds_bpermute. ----
+      int inc = cc;
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);   // row_shr:1
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);   // row_shr:2
+      inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);   // row_shr:4
+      const int exc = inc - cc;   // lane s: counts of the species before s; lane S: the totals
+      if (lane <= p.S) { L.rstart[lane] = (exc & 0xffff) + (exc >> 16); L.astart[lane] = exc & 0xffff; }
+      const int tab = (exc >> 16) | (inc << 16);   // {radial-only entries before species s, angular entries up to and including s}
 #pragma unroll
       for (int c = 0; c < NCHC; c++) {
+        const int t = __shfl(tab, spc[c]);
         if (pos[c] >= 0) {
           const bool ang = pos[c] < kMaxAng;
           const int w = ang ? pos[c] : pos[c] - kMaxAng;
-          int pr = w;   // species 0: the radial-only entries follow its as[1] angular ones
-          int lead = g.as[1];
-#pragma unroll
-          for (int s = 1; s < 8; s++)
-            if (s < p.S) {
-              const int st = ang ? g.as[s] : g.r2[s];
-              if (w >= st) { pr = g.rs[s] + (w - st); lead = g.as[s + 1] - g.as[s]; }
-            }
-          if (!ang) pr += lead;
+          const int pr = w + (ang ? (t & 0xffff) : ((unsigned)t >> 16));
           const float4 v = dd[c];
           L.rr[pr] = v.w;
           L.rfc[pr] = 0.5f * fcos_rev(v.w * half_inv_Rcr) + 0.5f;
@@ -1194,8 +1203,17 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
   for (int c = 0; c < GR; c++)
     if (lane + 64 * c < (p.aev_stride >> 2)) reinterpret_cast<float4*>(L.row)[lane + 64 * c] = pf.grow[c];
   const int nrad = hdr_nrad(h), nang = hdr_nang(h);
-  const Groups grp = unpack_groups(h);
-  store_starts(p, grp, nrad, nang, lane, L);
+  {
+    // starts of the species groups in the angular list (the pair table is built from them): lane s takes its count out of the
+    // header and a three-level DPP scan makes the prefix; lane S ends up with the total
+    const int word = lane < 4 ? h[2] : h[3];
+    const int ca = lane < 8 ? (word >> (8 * (lane & 3))) & 0xff : 0;
+    int inc = ca;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);   // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);   // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);   // row_shr:4
+    if (lane <= p.S) L.astart[lane] = inc - ca;
+  }
   wave_sync();   // the dE/dAEV row is read below
 
   // ---- radial stage, one lane per neighbour, straight from the prefetched registers.  A radial-only neighbour
@@ -1226,11 +1244,9 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     const int t = w;   // angular neighbours: index of the LDS accumulators
     float gx = 0.f, gy = 0.f, gz = 0.f;
 #ifndef ABL_NO_RAD
+    const int s = cl_species(j);   // the entry carries its species (cl_pack)
+    j = cl_index(j);
     if (live) {
-      int s = 0;
-#pragma unroll
-      for (int k = 1; k < 8; k++)
-        if (k < p.S) s += (w >= (ang ? grp.as[k] : grp.r2[k])) ? 1 : 0;
       const float4* gg4 = reinterpret_cast<const float4*>(L.row + s * NR);
       const float r = v.w;
       const float fc = 0.5f * fcos_rev(r * rev) + 0.5f;
