@@ -438,6 +438,14 @@ __device__ __forceinline__ hdr_t load_header(const AevArgs& a, int row) {   // r
   h[6] = __builtin_amdgcn_readfirstlane(h1.z); h[7] = __builtin_amdgcn_readfirstlane(h1.w);
   return h;
 }
+// The same through the scalar cache: the header is wave-uniform, a scalar load leaves eight vector moves out -- and it is counted
+// by lgkmcnt, not by the in-order vmcnt queue, so it does not wait for the force atomics the wave still has in flight.
+__device__ __forceinline__ hdr_t load_header_scalar(const AevArgs& a, int row) {   // row is wave-uniform
+  const int4* hp = a.cl_hdr + 2 * (size_t)row;
+  hdr_t h;
+  asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(h) : "s"(hp) : "memory");
+  return h;
+}
 // compact-list slot t (angular entries first, then the radial-only ones) -> index in the row's cl_xyz / cl_j
 __device__ __forceinline__ int slot_index(int t, int nang) { return t < nang ? t : kMaxAng + (t - nang); }
 template <int NCH, bool BWD, int GR>
@@ -1193,10 +1201,10 @@ __device__ __forceinline__ void scatter_neighbours(const AevArgs& a, const T* g,
 #endif
 }
 
-template <int NA, int NZ, int NCH, int GR, bool VIR>
-__device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t& h,
-                                                const Loaded<NCH, true, GR>& pf, int lane, float (&wv)[9],
-                                                const RepTab& rep, float& er BWD_STAMP_PARAMS) {
+template <int NA, int NZ, int NCH, int GR, bool VIR, typename PF>
+__device__ __forceinline__ void backward_centre(const AevParams& p, const AevArgs& a, FastLds& L, int row, const hdr_t h,
+                                                const Loaded<NCH, true, GR> pf, int lane, float (&wv)[9],
+                                                const RepTab& rep, float& er, PF&& before_final_scatter BWD_STAMP_PARAMS) {
   constexpr int NR = 16;
   const int centre = h[0];
 #pragma unroll
@@ -1652,6 +1660,7 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       wv[6] += gz * d.x; wv[7] += gz * d.y; wv[8] += gz * d.z;
     }
   }
+  before_final_scatter();   // the caller's loads for the wave's next centre: in front of the atomics in the in-order memory queue
   scatter_neighbours(a, L.gd, L.aj, nang, lane);
   fx = xor_sum<32>(xor_sum<16>(xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(fx))))));
   fy = xor_sum<32>(xor_sum<16>(xor_sum<8>(xor_sum<4>(xor_sum<2>(xor_sum<1>(fy))))));
@@ -1684,7 +1693,7 @@ __global__ __launch_bounds__(64 * kWavesB, ANI_BWD_MINW) void aev_backward_fast(
 #else
     BWD_STAMP(1);
 #endif
-    backward_centre<NA, NZ, NCH, GR, VIR>(p, a, L, row, hc, cur, lane, wv, rep, er, stamp_prev, stamp_acc);
+    backward_centre<NA, NZ, NCH, GR, VIR>(p, a, L, row, hc, cur, lane, wv, rep, er, [] {}, stamp_prev, stamp_acc);
     stamp_acc[6] += 1;
   }
   if (wave == 0 && lane == 0) {
@@ -1692,8 +1701,47 @@ __global__ __launch_bounds__(64 * kWavesB, ANI_BWD_MINW) void aev_backward_fast(
     atomicAdd(&g_bwd_stamps[8], stamp_acc[6]);
   }
 #else
-  ANI_PERSISTENT_LOOP(kWavesB, NCH, true, GR,
-                      (backward_centre<NA, NZ, NCH, GR, VIR>(p, a, L, row, hc, cur, lane, wv, rep, er)))
+  // Persistent loop of the backward pass (rows by ticket, a group's rows interleaved with the other groups': ANI_PERSISTENT_LOOP).
+  // A centre ends with its force atomics, and the memory queue is in order: loads issued behind them return behind them, so a
+  // wave that asks for its next centre's lists AFTER the scatter waits a whole atomic round trip per centre (without the global
+  // atomics the kernel takes 0.205 instead of 0.254 ms).  So the next centre's header (a scalar load: its own counter) and lists
+  // are requested in front of the final scatter, when only the registers of the centre's tail are live.
+  ANI_TICKETS_BEGIN(kWavesB)
+  const int kstop = tk_ctr ? tk_base + tk_share : kend;
+  auto rank_of = [&](int kx) -> int { return tk_ctr ? (kx - tk_base) * tk_ngrp + tk_grp : kx; };
+  auto row_of = [&](int kk) -> int {
+    const int kc = kk < a.kcount ? kk : a.kcount - 1;
+    return a.row_list ? __builtin_amdgcn_readfirstlane(a.row_list[a.k0 + kc]) : a.k0 + kc;
+  };
+  bool have = false;   // hc / cur already hold the centre of ticket k (requested in front of the previous centre's final scatter)
+  hdr_t hc;
+  Loaded<NCH, true, GR> cur;
+  while (k < kstop) {
+    ANI_TICKET_DRAW(tk_tn)
+    const int kk = rank_of(k);
+    const int row = row_of(kk);
+    const bool in_range = kk < a.kcount;
+    if (!have) {
+      hc = load_header_scalar(a, row);
+      if (hc[0] >= 0 && in_range) load_lists(p, a, row, hdr_nrad(hc), hdr_nang(hc), lane, cur);
+    }
+    have = false;
+    ANI_TICKET_TAKE(tk_k2)
+    if (hc[0] >= 0 && in_range) {
+      // header and lists go in by value: the hook overwrites hc / cur with the next centre's while this one finishes
+      backward_centre<NA, NZ, NCH, GR, VIR>(p, a, L, row, hc, cur, lane, wv, rep, er, [&]() {
+        const int kk1 = rank_of(k1);
+        if (k1 < kstop && kk1 < a.kcount) {   // wave-uniform
+          const int row1 = row_of(kk1);
+          hc = load_header_scalar(a, row1);
+          if (hc[0] >= 0) load_lists(p, a, row1, hdr_nrad(hc), hdr_nang(hc), lane, cur);
+          have = true;
+        }
+      });
+    }
+    ANI_TICKET_NEXT(tk_tn, tk_k2)
+  }
+  ANI_TICKETS_END(kWavesB)
 #endif
   if (rep.on) {
     double se = (double)er;
