@@ -118,6 +118,7 @@ struct ani_handle {
   int mlp_pipeline = 1;   // ani_set_option("mlp_pipeline"): 1 = large systems run all MLP layers as one launch of persistent workgroups
                           // with per-tile dependencies, 2 = at any size (measurement knob), 0 = one launch per layer
   int aev_fused = 1;         // ani_set_option("aev_fused"): 1 = neighbour compaction inside the forward AEV launch, 0 = its own kernel
+  int aev_sym_radial = 1;        // ani_set_option("aev_symmetric_radial"): see AevArgs::row_of_atom
   int aev_tickets_min = 40000;   // ani_set_option("aev_tickets_min"): launches of fewer rows keep the fixed stride
   int mlp_fused_sched = 1;   // ani_set_option("mlp_fused_schedule"): 1 = static first-fit schedule of the fused launch, 0 = a counter
   int mlp_fused = 1;   // ani_set_option("mlp_fused"): 1 = networks of three hidden layers run as one launch, a 128-row tile per
@@ -161,6 +162,7 @@ struct ani_handle {
   int sticky_flags = 0;   // every bit the device error word has ever shown the host (bit 1: LDS capacity, bit 2: MLP wait timeout)
   int max_numneigh = 0;
   DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
+  DevBuf<int> row_of_atom;   // [ntotal] AEV row of an atom, -1 for atoms that are no centres (AevArgs::row_of_atom)
   DevBuf<int> row_ctr;   // {ticket, waves done} pairs of the fused forward launch, one pair per row range (AevArgs::row_counter)
   DevBuf<float4> xyzs, cl_xyz;
   DevBuf<int4> row_info, cl_hdr;
@@ -436,7 +438,8 @@ int rebuild(ani_handle* h, hipStream_t st) {
     h->sticky_flags |= flag;
   }
   HIP_TRY(h, hipMemsetAsync(h->err_flag.p, 0, sizeof(int), st));
-  PrepOut o{h->nbr_off.p, h->row_of_centre.p, h->centre_of_row.p, h->row_info.p, h->bucket_info.p};
+  HIP_TRY(h, h->row_of_atom.reserve((size_t)std::max(h->ntotal, 1)));
+  PrepOut o{h->nbr_off.p, h->row_of_centre.p, h->centre_of_row.p, h->row_info.p, h->bucket_info.p, h->row_of_atom.p};
   launch_prepare(h->species.p, h->ilist.p, h->numneigh.p, nlocal, h->ntotal, m.S, nrows_cap, o, st);
   int info[kBucketInfoInts];
   HIP_TRY(h, hipMemcpyAsync(info, h->bucket_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
@@ -998,6 +1001,8 @@ AevArgs step_aev_args(ani_handle* h, const StepCtx& c, int rows) {
   // rows by ticket pay from a few rows per wave on (the ~5000 resident waves of a launch each draw three tickets before their
   // first centre): below that the fixed stride is as good and starts at once (option "aev_tickets_min")
   if (a.kcount < h->aev_tickets_min) a.row_counter = nullptr;
+  // a centre may read its neighbours' dE/dAEV rows only when every row of the step has been through the MLP: not in a split step
+  a.row_of_atom = (rows == 0 && h->aev_sym_radial) ? h->row_of_atom.p : nullptr;
   return a;
 }
 
@@ -1238,7 +1243,7 @@ void ani_destroy(ani_handle* h) {
     if (n.b_out64) (void)hipFree(n.b_out64);
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
-  h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release(); h->row_ctr.release();
+  h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release(); h->row_ctr.release(); h->row_of_atom.release();
   h->xyzs.release(); h->cl_xyz.release(); h->cl_hdr.release(); h->cl_j.release(); h->row_info.release(); h->row_flag.release(); h->row_list.release(); h->row_count.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->origin.release();
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
@@ -1615,6 +1620,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   if (strcmp(name, "mlp_fused") == 0) {
     if (value < 0 || value > 3) { h->err = "mlp_fused must be 0, 1, 2 or 3"; return ANI_ERR_ARG; }
     h->mlp_fused = value;
+    return ANI_OK;
+  }
+  if (strcmp(name, "aev_symmetric_radial") == 0) {
+    h->aev_sym_radial = value != 0;
     return ANI_OK;
   }
   if (strcmp(name, "aev_tickets_min") == 0) {

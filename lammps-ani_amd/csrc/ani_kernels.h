@@ -170,6 +170,7 @@ struct PrepOut {
   int* centre_of_row;   // [nrows_cap] (-1 = padding)
   int4* row_info;       // [nrows_cap] per AEV row: {i, list begin, list length, ii}; i = -1 for padding rows
   int* bucket_info;     // [kBucketInfoInts]: count[s], row_start[s], nrows, bad_species flag, max numneigh, species-present mask
+  int* row_of_atom;     // [ntotal] or NULL: the AEV row of an atom that is a centre, -1 for every other atom (ghosts)
 };
 size_t prepare_scratch_ints(int nlocal);   // size of PrepOut::row_of_centre (rows + scratch of the two kernels)
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
@@ -206,6 +207,10 @@ struct AevArgs {
   // (every row: k0 = 0, kcount = nrows).  The generic kernels always take every row.
   const int* row_list;
   int k0, kcount;
+  // backward, fast path: AEV row of an atom (-1: not a centre here) -- with it a centre collects BOTH radial terms of a pair with a
+  // local neighbour (its own and, read from the neighbour's dE/dAEV row, the neighbour's) and scatters nothing to that neighbour;
+  // NULL: every radial gradient is scattered to the neighbour
+  const int* row_of_atom;
   // forward launch with the compaction inside: kTicketGroups x {next ticket, waves done} at a stride of kTicketStride ints -- its
   // waves draw their rows from their group's counter instead of a fixed stride (a group's last wave out resets the pair for the
   // next launch); NULL: fixed stride

@@ -1254,12 +1254,25 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
 #ifndef ABL_NO_RAD
     const int s = cl_species(j);   // the entry carries its species (cl_pack)
     j = cl_index(j);
+    // A pair's two radial terms -- E_centre's and E_neighbour's dependence on their distance -- differ only in the dE/dAEV
+    // row they are weighted with (same Gaussians, same cutoff factor).  When the neighbour is a centre of this launch too, the
+    // centre reads the neighbour's row (its block for the centre's species) and takes BOTH terms' force on itself; the
+    // neighbour does the same from its side, and neither scatters a radial gradient to the other: two thirds of the kernel's
+    // global atomics were those (it waits for its atomics, not for its arithmetic).  Ghosts have no row here: their term is
+    // scattered as before and comes back through the ghost exchange.  sym: this lane's neighbour is handled that way.
+    float gsx = 0.f, gsy = 0.f, gsz = 0.f;   // sym: what the centre adds to its own force beyond (gx, gy, gz)
+    int rj = -1;
+#ifndef ANI_RAD_NOREC
+    if (a.row_of_atom && live) rj = a.row_of_atom[j];
+#endif
+    const bool sym = rj >= 0;
     if (live) {
       const float4* gg4 = reinterpret_cast<const float4*>(L.row + s * NR);
+      const float4* qq4 = reinterpret_cast<const float4*>(a.gaev + (size_t)(sym ? rj : row) * p.aev_stride + hdr_species(h) * NR);
       const float r = v.w;
       const float fc = 0.5f * fcos_rev(r * rev) + 0.5f;
       const float dfc = -0.5f * p.pi_over_Rcr * fsin_rev(r * rev);
-      float dEdr = 0.f;
+      float dEdr = 0.f, dEdn = 0.f;   // d/dr of the centre's energy, of the neighbour's
 #ifndef ANI_RAD_NOREC
       // The sixteen Gaussians exp2(cR (r - ShfR_k)^2) from six exponentials: in each half of the shifts, around its midpoint
       // sc, d_k = dc - m Delta (m = k - 3.5) and exp2(cR d_k^2) = E H^(2m) C_|m| with E = exp2(cR dc^2), H = exp2(-cR dc Delta),
@@ -1281,10 +1294,15 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
           e[3] = dn * C0; dn *= Ri; e[2] = dn * C1; dn *= Ri; e[1] = dn * C2; dn *= Ri; e[0] = dn * C3;
           const float4 ga = gg4[2 * hf], gb = gg4[2 * hf + 1];
           const float gk[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+          float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
+          if (sym) { qa = qq4[2 * hf]; qb = qq4[2 * hf + 1]; }
+          const float qk[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
           float dr = dc + 3.5f * p.dShfR;   // r - ShfR[8 hf]
 #pragma unroll
           for (int kk = 0; kk < 8; kk++) {
-            dEdr = fmaf(gk[kk] * e[kk], fmaf(kf, dr, dfc), dEdr);
+            const float tk = e[kk] * fmaf(kf, dr, dfc);
+            dEdr = fmaf(gk[kk], tk, dEdr);
+            dEdn = fmaf(qk[kk], tk, dEdn);
             dr -= p.dShfR;
           }
         }
@@ -1303,8 +1321,10 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
         }
       }
 #endif
-      const float sc = 0.25f * dEdr * frcp(r);
+      const float inv_r = frcp(r);
+      const float sc = 0.25f * dEdr * inv_r, scn = 0.25f * dEdn * inv_r;
       gx = sc * v.x; gy = sc * v.y; gz = sc * v.z;
+      gsx = scn * v.x; gsy = scn * v.y; gsz = scn * v.z;
       if (rep.on && r < rep.cutoff) {
         // pairwise repulsion (ani_kernels_rep.hip has the formulas): half of e(r) per list entry.  The pair function in
         // fp32 like the rest of this precision mode, but its argument from the fp64 positions: the wall is steep
@@ -1325,7 +1345,9 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
           er += 0.5f * g * fcr;
           const float sr = 0.5f * (dg * fcr + g * dfcr);
           const double inv = 1.0 / r64;
-          gx += sr * (float)(ddx * inv); gy += sr * (float)(ddy * inv); gz += sr * (float)(ddz * inv);
+          const float rx = sr * (float)(ddx * inv), ry = sr * (float)(ddy * inv), rz = sr * (float)(ddz * inv);
+          gx += rx; gy += ry; gz += rz;
+          if (sym) { gsx += rx; gsy += ry; gsz += rz; }   // the neighbour's entry for this pair holds the same half of the pair term
         }
       }
     }
@@ -1334,6 +1356,15 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
       L.ad[t] = v;
       L.afc[t] = 0.5f * fcos_rev(v.w * revA) + 0.5f;
       L.aj[t] = j;
+      if (sym) {   // radial terms settled here on the centre's side; the accumulator starts empty for the angular stage
+        fx += gx + gsx; fy += gy + gsy; fz += gz + gsz;
+        if constexpr (VIR) {
+          wv[0] += gx * v.x; wv[1] += gx * v.y; wv[2] += gx * v.z;
+          wv[3] += gy * v.x; wv[4] += gy * v.y; wv[5] += gy * v.z;
+          wv[6] += gz * v.x; wv[7] += gz * v.y; wv[8] += gz * v.z;
+        }
+        gx = gy = gz = 0.f;
+      }
       L.gd[3 * t] = gx; L.gd[3 * t + 1] = gy; L.gd[3 * t + 2] = gz;
     }
     // radial-only neighbours: finished here (scattered at once; ONE merged scatter per centre -- angular + radial-only +
@@ -1341,18 +1372,23 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     // burst at the end of the centre instead of two spread over it)
     const int lo = min(max(nang - base, 0), 64), hi = min(nrad - base, 64);   // radial-only lanes of this chunk: [lo, hi)
     if (hi > lo) {   // wave-uniform
+      const bool out = live && !ang && !sym;            // a radial-only neighbour whose gradient has to travel
+      const unsigned long long mout = __ballot(out);
       if (live && !ang) {
-        fx += gx; fy += gy; fz += gz;
+        fx += gx + gsx; fy += gy + gsy; fz += gz + gsz;   // (gs = 0 unless sym)
         if constexpr (VIR) {
           wv[0] += gx * v.x; wv[1] += gx * v.y; wv[2] += gx * v.z;
           wv[3] += gy * v.x; wv[4] += gy * v.y; wv[5] += gy * v.z;
           wv[6] += gz * v.x; wv[7] += gz * v.y; wv[8] += gz * v.z;
         }
-        L.gt[3 * (lane - lo)] = gx; L.gt[3 * (lane - lo) + 1] = gy; L.gt[3 * (lane - lo) + 2] = gz;
-        L.jt[lane - lo] = j;
+        if (out) {
+          const int q = lanes_below(mout);
+          L.gt[3 * q] = gx; L.gt[3 * q + 1] = gy; L.gt[3 * q + 2] = gz;
+          L.jt[q] = j;
+        }
       }
       wave_sync();
-      scatter_neighbours(a, L.gt, L.jt, hi - lo, lane);
+      scatter_neighbours(a, L.gt, L.jt, __popcll(mout), lane);
       wave_sync();   // the staging buffer is reused by the next chunk
     }
   }

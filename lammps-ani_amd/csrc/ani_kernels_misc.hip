@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void prepare_rows_kernel(const int* __restrict
   if (row < nrows_cap) {
     o.centre_of_row[row] = ii;
     o.row_info[row] = make_int4(i, off, len, ii);
+    if (o.row_of_atom) o.row_of_atom[i] = row;
   }
 }
 
@@ -193,6 +194,7 @@ void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numne
   note_launch_error(hipMemsetAsync(o.centre_of_row, 0xff, sizeof(int) * (size_t)nrows_cap, st));
   note_launch_error(hipMemsetAsync(o.row_info, 0xff, sizeof(int4) * (size_t)nrows_cap, st));
   note_launch_error(hipMemsetAsync(o.bucket_info, 0, sizeof(int) * kBucketInfoInts, st));
+  if (o.row_of_atom) note_launch_error(hipMemsetAsync(o.row_of_atom, 0xff, sizeof(int) * (size_t)(ntotal > 0 ? ntotal : 1), st));
   hipLaunchKernelGGL(prepare_count_kernel, dim3(nchunks), dim3(1024), 0, st, d_species, d_ilist, d_numneigh, nlocal, ntotal, S, o,
                      rank, chunk_tot);
   hipLaunchKernelGGL(prepare_rows_kernel, dim3(nlocal > 0 ? (nlocal + 255) / 256 : 1), dim3(256), 0, st, d_species, d_ilist,

@@ -256,6 +256,28 @@ def test_chained_mlp_launch_equals_per_layer_launches(model_cache, hip):
         ani.close()
 
 
+def test_symmetric_radial_collection_equals_the_scatter(model_cache, hip):
+    """Option aev_symmetric_radial (default 1): a centre takes both radial terms of a pair with a local neighbour on itself (the
+    neighbour's read from the neighbour's dE/dAEV row) and scatters no radial gradient to it; 0 = every radial gradient is
+    scattered to the neighbour.  The same forces, energy and virial: water, a 7-species box, an ANI-1x box with the pairwise
+    repulsion (whose pair term is split between the two entries of a pair), each with its periodic ghosts (which have no row and
+    keep the scatter)."""
+    cases = [("ani2x", hx.decompose(hx.water_box(3000, seed=3)), False), ("ani2x", hx.decompose(hx.random_box(1200, 7, 26.0, seed=6)), False),
+             ("ani1x", hx.decompose(hx.random_box(900, 4, 24.0, seed=8), cutoff=5.2), True)]
+    for kind, inp, rep in cases:
+        p = model_cache(kind, 2, 79, repulsion=rep)
+        ani = hip.ANI(p, 0)
+        out = []
+        for sym in (1, 0):
+            ani.set_option("aev_symmetric_radial", sym)
+            out.append(ani.compute(inp, ago=0, eflag_atom=True, vflag=True))
+        fmax = max(1.0, float(np.abs(out[1]["force"]).max()))
+        assert np.abs(out[0]["force"] - out[1]["force"]).max() < 0.02 * F_TOL * fmax
+        assert abs(out[0]["energy"] - out[1]["energy"]) < 1e-5
+        assert np.abs(out[0]["virial"] - out[1]["virial"]).max() < 2e-3 * max(1.0, inp.nlocal / 100.0)
+        ani.close()
+
+
 def test_rows_by_ticket_equal_rows_by_stride(model_cache, hip):
     """Option aev_tickets_min: large launches hand the AEV rows to the waves by ticket (contiguous blocks per group of workgroups
     in the forward launch, the groups' rows interleaved in the backward launch), small ones at a fixed stride.  Forced on for
