@@ -217,7 +217,8 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *   "aev_symmetric_radial" (default 1): in the backward pass a centre takes both radial terms of a pair with a neighbour that is
  *     a centre of the same call on itself (the neighbour's term read from the neighbour's dE/dAEV row) and scatters no radial
  *     gradient to it -- two thirds of the pass's global atomics; ghost neighbours keep the scatter.  0 = scatter every radial
- *     gradient.  Same results to the order of the fp32 sums.  Not used by the split step (ani_step_begin ...).
+ *     gradient.  Same results to the order of the fp32 sums.  Relies on what a LAMMPS full list guarantees (and the built-in
+ *     list builder keeps): j is in i's list exactly when i is in j's.  Not used by the split step (ani_step_begin ...).
  *   "aev_tickets_min" (default 40000): AEV launches over at least this many rows hand their rows to the waves by ticket (64 groups
  *     of workgroups, a counter each) instead of at a fixed stride; smaller launches keep the stride.  Same results.
  *   "mlp_fused_schedule" (default 1): which workgroup of the fused launch runs which tiles is decided on the host, once per
