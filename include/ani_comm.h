@@ -91,6 +91,11 @@ int ani_comm_reverse_unpack(ani_comm* c, double* d_f, void* stream);
  * Neighbor::decide) */
 int ani_comm_allreduce_f64(ani_comm* c, double* d_buf, int n, int op, void* stream);
 
+/* counters of this communicator: "forward_exchanges", "reverse_exchanges" (calls of ani_comm_forward / ani_comm_reverse_send that
+ * had something to move), "alltoalls" (every grouped exchange posted, the rebuild-time ones included), "broken" (1 after an RCCL
+ * call failed inside an exchange: every later call fails fast instead of queueing into a half-posted group); -1 = unknown name */
+long long ani_comm_get_stat(const ani_comm* c, const char* name);
+
 /* options: "self_through_rccl" (default 0): 1 sends the rank's own chunk through ncclSend / ncclRecv as well instead of a
  * device copy -- a test knob that drives the RCCL point-to-point path on a single GPU */
 int ani_comm_set_option(ani_comm* c, const char* name, int value);

@@ -75,6 +75,8 @@ double ani_cutoff_angular(const ani_handle* h);
  *                          the LAMMPS full list flattened in ilist order, neighbour indices already masked with
  *                          NEIGHMASK (src/pair_ani.cpp:129-150); read only when ago == 0 and cached on the device
  *                          otherwise (src/ani_csrc/ani.cpp:213-229).  numneigh[ii] belongs to centre ilist_unique[ii].
+ *                          A LAMMPS full list is symmetric between owned atoms (j in i's list exactly when i in j's); a list
+ *                          that is not is accepted and costs the symmetric radial collection (option aev_symmetric_radial).
  *   ago                    neighbor->ago: 0 = the list was rebuilt this step
  *   eflag_atom, vflag      whether out_atomic_energies / out_virial are wanted
  *   out_energy             total energy of the nlocal centres, self energies included
@@ -190,7 +192,8 @@ typedef struct {
   int aev_active_length;           /* columns in use: the AEV entries of the species present in the system */
   int error_flags;                 /* every bit the device error word has shown so far (latched at host reads and at each
                                       re-neighbouring): 1 = LDS neighbour capacity exceeded, 2 = a wait inside the
-                                      one-launch MLP kernel timed out.  The device entry points cannot return these (nothing
+                                      one-launch MLP kernel timed out, 8 = a caller's list was not symmetric between owned
+                                      atoms (informational: option aev_symmetric_radial was off for that epoch).  The device entry points cannot return these (nothing
                                       synchronises; the energy becomes NaN): a loop that finds a NaN energy reads this */
 } ani_debug_view;
 int ani_debug_get(ani_handle* h, ani_debug_view* out);
@@ -218,7 +221,10 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *     a centre of the same call on itself (the neighbour's term read from the neighbour's dE/dAEV row) and scatters no radial
  *     gradient to it -- two thirds of the pass's global atomics; ghost neighbours keep the scatter.  0 = scatter every radial
  *     gradient.  Same results to the order of the fp32 sums.  Relies on what a LAMMPS full list guarantees (and the built-in
- *     list builder keeps): j is in i's list exactly when i is in j's.  Not used by the split step (ani_step_begin ...).
+ *     list builder keeps): j is in i's list exactly when i is in j's.  A list handed in by the caller (ani_compute_full,
+ *     ani_compute_half, ani_compute_full_device at ago == 0) is CHECKED for this once per epoch (a hash sum over the entries
+ *     between owned atoms, ~0.1 ms at 100 000 atoms); an epoch whose list fails runs with the scatter of every term, sets bit 8
+ *     of error_flags and says so once on stderr.  Not used by the split step (ani_step_begin ...).
  *   "aev_tickets_min" (default 40000): AEV launches over at least this many rows hand their rows to the waves by ticket (64 groups
  *     of workgroups, a counter each) instead of at a fixed stride; smaller launches keep the stride.  Same results.
  *   "mlp_fused_schedule" (default 1): which workgroup of the fused launch runs which tiles is decided on the host, once per

@@ -27,7 +27,7 @@ EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani
 COMM_EXPORTS = ["ani_comm_get_unique_id", "ani_comm_create", "ani_comm_destroy", "ani_comm_last_error", "ani_comm_rank",
                 "ani_comm_size", "ani_comm_plan", "ani_comm_exchange_counts", "ani_comm_alltoallv", "ani_comm_set_epoch",
                 "ani_comm_set_epoch_host", "ani_comm_set_ghost_order", "ani_comm_forward", "ani_comm_reverse", "ani_comm_reverse_send", "ani_comm_reverse_unpack",
-                "ani_comm_allreduce_f64", "ani_comm_set_option"]
+                "ani_comm_allreduce_f64", "ani_comm_set_option", "ani_comm_get_stat"]
 
 
 class AniError(RuntimeError):
@@ -126,6 +126,8 @@ def lib():
         L.ani_comm_reverse_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ani_comm_allreduce_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ani_comm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.ani_comm_get_stat.argtypes = [C.c_void_p, C.c_char_p]
+        L.ani_comm_get_stat.restype = C.c_longlong
         L.ani_phase_timing.argtypes = [C.c_void_p, C.c_int]
         L.ani_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _lib = L
@@ -301,14 +303,40 @@ class NativeComm:
 
     @classmethod
     def from_torch(cls, device_index: int, group=None):
-        """bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast as an object"""
+        """bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast as an object.
+        Every rank runs the SAME sequence of collectives whatever fails where: rank 0 broadcasts (status, id) even when it
+        could not make an id, and the ranks agree on the outcome of ani_comm_create before anybody uses the communicator --
+        so a caller's fallback to another transport is taken by all ranks or by none."""
         import torch.distributed as dist
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box = [("ok", cls.unique_id())]
+            except Exception as e:   # librccl missing, ncclGetUniqueId failed: the peers must hear about it
+                box = [("error", str(e))]
         if world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        return cls(world, rank, box[0], device_index)
+        status, payload = box[0]
+        if status != "ok":
+            raise AniError(f"rank 0 could not make an RCCL id: {payload}")
+        comm, err = None, None
+        try:
+            comm = cls(world, rank, payload, device_index)
+        except AniError as e:
+            err = e
+        if world > 1:
+            oks = [None] * world
+            dist.all_gather_object(oks, err is None, group=group)
+            if not all(oks):
+                if comm is not None:
+                    comm.close()
+                raise AniError(f"ani_comm_create failed on rank(s) {[r for r, ok in enumerate(oks) if not ok]}"
+                               + (f": {err}" if err is not None else ""))
+        elif err is not None:
+            raise err
+        return comm
 
     def __init__(self, nranks: int, rank: int, id_bytes: bytes, device_index: int = 0):
         self._lib = lib()
@@ -337,6 +365,10 @@ class NativeComm:
 
     def set_option(self, name: str, value: int):
         self._check(self._lib.ani_comm_set_option(self._h, name.encode(), int(value)))
+
+    def stat(self, name: str) -> int:
+        """ani_comm_get_stat: 'forward_exchanges', 'reverse_exchanges', 'alltoalls', 'broken' """
+        return int(self._lib.ani_comm_get_stat(self._h, name.encode()))
 
     def exchange_counts(self, send_counts, stream=None):
         sc = np.ascontiguousarray(send_counts, dtype=np.int64)

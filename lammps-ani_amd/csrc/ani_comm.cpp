@@ -85,7 +85,9 @@ struct ani_comm {
   int nranks = 1, rank = 0, device = 0;
   ncclComm_t comm = nullptr;
   bool self_rccl = false;
-  std::string err;
+  bool broken = false;   // an RCCL call failed inside an exchange: peers may be mid-way through it, nothing more is sent
+  long long n_forward = 0, n_reverse = 0, n_a2a = 0;   // exchanges posted (ani_comm_get_stat)
+  std::string err, err_first;
   // epoch
   std::vector<int64_t> sc, rc, so, ro;
   int64_t nsend = 0, nrecv = 0;
@@ -143,16 +145,30 @@ int grow(ani_comm* c, T** p, size_t* cap, size_t n) {
 int a2a_bytes(ani_comm* c, const char* send, const int64_t* sc, const int64_t* so, char* recv, const int64_t* rc, const int64_t* ro,
               size_t item, hipStream_t st) {
   Rccl* r = rccl();
+  if (c->broken) { c->err = "the communicator is unusable after an earlier RCCL failure: " + c->err_first; return ANI_ERR_DEVICE; }
+  c->n_a2a++;
   bool any = false;
   for (int p = 0; p < c->nranks; p++) any = any || ((p != c->rank || c->self_rccl) && (sc[p] > 0 || rc[p] > 0));
   if (any) {
     COMM_NCCL(c, r->GroupStart());
-    for (int p = 0; p < c->nranks; p++) {
+    // a failed Send / Recv must not return from inside the bracket: the group would stay open on this thread and every later
+    // RCCL call (the next exchange, an all-reduce) would be queued into it and never launched -- a silent hang.  The first
+    // error is kept, the group is closed, the communicator is marked unusable.
+    ncclResult_t bad = ncclSuccess;
+    const char* what = "";
+    for (int p = 0; p < c->nranks && bad == ncclSuccess; p++) {
       if (p == c->rank && !c->self_rccl) continue;
-      if (sc[p] > 0) COMM_NCCL(c, r->Send(send + (size_t)so[p] * item, (size_t)sc[p] * item, ncclChar, p, c->comm, st));
-      if (rc[p] > 0) COMM_NCCL(c, r->Recv(recv + (size_t)ro[p] * item, (size_t)rc[p] * item, ncclChar, p, c->comm, st));
+      if (sc[p] > 0) { bad = r->Send(send + (size_t)so[p] * item, (size_t)sc[p] * item, ncclChar, p, c->comm, st); what = "ncclSend"; }
+      if (bad == ncclSuccess && rc[p] > 0) { bad = r->Recv(recv + (size_t)ro[p] * item, (size_t)rc[p] * item, ncclChar, p, c->comm, st); what = "ncclRecv"; }
     }
-    COMM_NCCL(c, r->GroupEnd());
+    const ncclResult_t end = r->GroupEnd();
+    if (bad == ncclSuccess && end != ncclSuccess) { bad = end; what = "ncclGroupEnd"; }
+    if (bad != ncclSuccess) {
+      c->broken = true;
+      c->err_first = std::string(what) + ": " + r->GetErrorString(bad);
+      c->err = c->err_first;
+      return ANI_ERR_DEVICE;
+    }
   }
   if (!c->self_rccl) {
     const int me = c->rank;
@@ -234,6 +250,15 @@ int ani_comm_plan(int nranks, const int64_t* send_counts, const int64_t* recv_co
     if (send_counts[p] < 0 || recv_counts[p] < 0) return ANI_ERR_ARG;
   plan(nranks, send_counts, recv_counts, send_off, recv_off, nsend, nrecv);
   return ANI_OK;
+}
+
+long long ani_comm_get_stat(const ani_comm* c, const char* name) {
+  if (!c || !name) return -1;
+  if (strcmp(name, "forward_exchanges") == 0) return c->n_forward;
+  if (strcmp(name, "reverse_exchanges") == 0) return c->n_reverse;
+  if (strcmp(name, "alltoalls") == 0) return c->n_a2a;
+  if (strcmp(name, "broken") == 0) return c->broken ? 1 : 0;
+  return -1;
 }
 
 int ani_comm_set_option(ani_comm* c, const char* name, int value) {
@@ -334,6 +359,7 @@ int ani_comm_forward(ani_comm* c, double* d_x, int nlocal, void* stream) {
   if (c->nsend == 0 && c->nrecv == 0) return ANI_OK;
   COMM_HIP(c, hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
+  c->n_forward++;
   const int rc = ani_md_pack_ghosts(d_x, c->d_send_idx, c->d_send_shift, (int)c->nsend, c->stage, st);
   if (rc) { c->err = std::string("pack kernel: ") + hipGetErrorString((hipError_t)rc); return ANI_ERR_DEVICE; }
   if (!c->d_ghost_of)
@@ -351,6 +377,7 @@ int ani_comm_reverse_send(ani_comm* c, const double* d_f, int nlocal, void* stre
   if (!c || !d_f || nlocal < 0) return ANI_ERR_ARG;
   if (c->nsend == 0 && c->nrecv == 0) return ANI_OK;
   COMM_HIP(c, hipSetDevice(c->device));
+  c->n_reverse++;
   // the roles swap: what came in as ghosts goes back to where it came from
   const double* src = d_f + 3 * (size_t)nlocal;
   if (c->d_ghost_of) {
@@ -379,6 +406,7 @@ int ani_comm_reverse(ani_comm* c, double* d_f, int nlocal, void* stream) {
 int ani_comm_allreduce_f64(ani_comm* c, double* d_buf, int n, int op, void* stream) {
   if (!c || !d_buf || n < 0 || (op != 0 && op != 1)) return ANI_ERR_ARG;
   if (n == 0) return ANI_OK;
+  if (c->broken) { c->err = "the communicator is unusable after an earlier RCCL failure: " + c->err_first; return ANI_ERR_DEVICE; }
   COMM_HIP(c, hipSetDevice(c->device));
   COMM_NCCL(c, rccl()->AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->comm, (hipStream_t)stream));
   return ANI_OK;

@@ -163,6 +163,10 @@ struct ani_handle {
   int max_numneigh = 0;
   DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
   DevBuf<int> row_of_atom;   // [ntotal] AEV row of an atom, -1 for atoms that are no centres (AevArgs::row_of_atom)
+  DevBuf<unsigned> sym_acc;  // [ntotal] scratch of the list symmetry check (launch_list_symmetry)
+  bool warned_asymmetric = false;
+  bool list_is_ours = false; // the installed list was built by ani_build_list*: symmetric by construction
+  bool list_symmetric = true;  // this epoch's list passed the check (or is ours): the symmetric radial collection may run
   DevBuf<int> row_ctr;   // {ticket, waves done} pairs of the fused forward launch, one pair per row range (AevArgs::row_counter)
   DevBuf<float4> xyzs, cl_xyz;
   DevBuf<int4> row_info, cl_hdr;
@@ -452,6 +456,27 @@ int rebuild(ani_handle* h, hipStream_t st) {
   {
     const int rcs = specialize(h, info[2 * kMaxSpecies + 3]);
     if (rcs) return rcs;
+  }
+  // A caller's list is checked for symmetry once per epoch (the symmetric radial collection relies on it); one that fails
+  // runs with the scatter of every term, which is right for any list.  Said once.
+  h->list_symmetric = true;
+  if (!h->list_is_ours && h->use_single && h->aev_sym_radial && nlocal > 0) {
+    HIP_TRY(h, h->sym_acc.reserve((size_t)std::max(h->ntotal, 1)));
+    launch_list_symmetry(h->ilist.p, h->nbr_off.p, h->numneigh.p, h->jraw.p, h->row_of_atom.p, nlocal, h->ntotal, h->sym_acc.p,
+                         h->bucket_info.p, st);   // bucket_info has been read: its first word carries the verdict
+    int bad = 0;
+    HIP_TRY(h, hipMemcpyAsync(&bad, h->bucket_info.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    HIP_TRY(h, take_launch_error());
+    if (bad) {
+      h->list_symmetric = false;
+      h->sticky_flags |= 8;
+      if (!h->warned_asymmetric) {
+        h->warned_asymmetric = true;
+        fprintf(stderr, "libani_hip: the neighbour list is not symmetric between owned atoms (j in i's list without i in j's): "
+                        "aev_symmetric_radial is off for such epochs, every radial term is scattered\n");
+      }
+    }
   }
   // neighbour segments grouped by species: what lets the AEV kernels accumulate without atomics
   launch_sort_jlist(h->species.p, h->nbr_off.p, h->numneigh.p, h->jraw.p, h->jlist.p, nlocal, m.S, info[2 * kMaxSpecies + 3], st);
@@ -1002,7 +1027,7 @@ AevArgs step_aev_args(ani_handle* h, const StepCtx& c, int rows) {
   // first centre): below that the fixed stride is as good and starts at once (option "aev_tickets_min")
   if (a.kcount < h->aev_tickets_min) a.row_counter = nullptr;
   // a centre may read its neighbours' dE/dAEV rows only when every row of the step has been through the MLP: not in a split step
-  a.row_of_atom = (rows == 0 && h->aev_sym_radial) ? h->row_of_atom.p : nullptr;
+  a.row_of_atom = (rows == 0 && h->aev_sym_radial && h->list_symmetric) ? h->row_of_atom.p : nullptr;
   return a;
 }
 
@@ -1289,6 +1314,7 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
     // and a loop notices steps later): the radial lists get the capacity of the longest candidate list from the start.
     // (The 3/4 estimate of the host entry points saves LDS only; they repeat the step when it was too small.)
     h->ap.full_cap = h->ap_run.full_cap = 1;
+    h->list_is_ours = false;
     rc = rebuild(h, st);
     if (rc) return rc;
     h->have_list = true;
@@ -1438,6 +1464,7 @@ int build_list(ani_handle* h, int ntotal, int nlocal, const int* d_species, cons
   launch_nbr_fill(nlocal, ntotal, g, s, cutneigh, h->nbr_off.p, h->jraw.p, h->ilist.p, st);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, take_launch_error());
+  h->list_is_ours = true;
   rc = rebuild(h, st);
   if (rc) return rc;
   h->have_list = true;
@@ -1490,6 +1517,18 @@ int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
   if (!coordinates || !out_force || !out_energy) { h->err = "null pointer argument"; return ANI_ERR_ARG; }
   HIP_TRY(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
+  if (h->comm && h->use_cuaev && !h->ap_run.full_cap) {
+    // With a communicator attached the step ends in a matched send / receive with every peer (finish_host), posted before
+    // the capacity word is read.  The retry below would post a SECOND exchange on this rank alone: its peers have added the
+    // overflowed step's ghost forces already and pair the extra message with their next step (forces one step stale, or a
+    // hang at destroy).  So no retry can happen here: the lists are sized for the worst case from the start, as for the
+    // device entry points.
+    h->ap.full_cap = h->ap_run.full_cap = 1;
+    if (ago != 0) {
+      rc = rebuild(h, st);
+      if (rc) return rc;
+    }
+  }
   if (ago == 0) {
     if (!species || !ilist_unique || !numneigh || (npairs > 0 && !jlist)) { h->err = "null list pointer with ago == 0"; return ANI_ERR_ARG; }
     h->ntotal = ntotal; h->nlocal = nlocal; h->npairs = npairs;
@@ -1505,6 +1544,7 @@ int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
     HIP_TRY(h, hipMemcpyAsync(h->numneigh.p, numneigh, sizeof(int) * (size_t)nlocal, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->jraw.p, jlist, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice, st));
     h->have_list = false;
+    h->list_is_ours = false;
     rc = rebuild(h, st);
     if (rc) return rc;
     h->have_list = true;
@@ -1517,7 +1557,7 @@ int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
   rc = run_step(h, h->x64.p, eflag_atom, vflag, h->f64.p, /*accumulate=*/0, h->ev.p, h->eatom.p, st);
   if (rc) return rc;
   rc = finish_host(h, ntotal, nlocal, eflag_atom, vflag, out_energy, out_force, out_atomic_energies, out_virial);
-  if (rc == ANI_ERR_CAPACITY && h->use_cuaev && !h->ap_run.full_cap) {
+  if (rc == ANI_ERR_CAPACITY && h->use_cuaev && !h->ap_run.full_cap && !h->comm) {
     // The screened radial lists are sized for 3/4 of the longest candidate list; a system denser than that inside Rcr
     // (small skin, compressed fluid) is input the reference handles, so the step is repeated once with the capacity of
     // the full list and the setting kept for the rest of the run.  An overflow that survives (more than kMaxAng

@@ -175,6 +175,9 @@ struct PrepOut {
 size_t prepare_scratch_ints(int nlocal);   // size of PrepOut::row_of_centre (rows + scratch of the two kernels)
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
                     const PrepOut& o, hipStream_t st);
+// 1 in *d_out unless every entry i -> j between two centres of the list has its mirror j -> i (ani_kernels_misc.hip); d_acc: [ntotal] scratch
+void launch_list_symmetry(const int* d_ilist, const int* d_nbr_off, const int* d_numneigh, const int* d_jraw, const int* d_row_of_atom,
+                          int nlocal, int ntotal, unsigned* d_acc, int* d_out, hipStream_t st);
 
 #ifndef ANI_TK_GROUPS
 #define ANI_TK_GROUPS 64

@@ -201,6 +201,52 @@ void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numne
                      d_numneigh, nlocal, ntotal, S, nrows_cap, o, rank, chunk_tot);
 }
 
+// ---- is the list symmetric? ------------------------------------------------------------------------------------------
+// The backward kernel's symmetric radial collection (AevArgs::row_of_atom) takes both radial terms of a pair on the centre's
+// side and scatters nothing to a neighbour that is itself a centre: right only if j is in i's list exactly when i is in j's.
+// A list built here is (one cutoff test in fp64 for both directions); a caller's list may not be (exclusions applied to one
+// direction, a truncated list).  Check of a caller's list, once per epoch: every entry i -> j between two centres adds
+// g(i, j) = g(j, i) to i's sum and subtracts it from j's; all sums end at zero if (not only if: a 32-bit hash sum) the
+// entries come in mirrored pairs.  One wave per centre, one atomic per entry.
+__device__ __forceinline__ unsigned pair_hash(unsigned a, unsigned b) {
+  const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+  unsigned h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
+  h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13;
+  return h | 1u;
+}
+__global__ __launch_bounds__(256) void list_symmetry_kernel(const int* __restrict__ ilist, const int* __restrict__ nbr_off,
+                                                            const int* __restrict__ numneigh, const int* __restrict__ jraw,
+                                                            const int* __restrict__ row_of_atom, int nlocal, int ntotal,
+                                                            unsigned* __restrict__ acc) {
+  const int ii = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ii >= nlocal) return;
+  const int i = ilist[ii], n = numneigh[ii];   // numneigh[ii] belongs to centre ilist[ii]
+  const int* seg = jraw + nbr_off[ii];
+  unsigned own = 0;
+  for (int k = lane; k < n; k += 64) {
+    const int j = seg[k];
+    if (j < 0 || j >= ntotal || row_of_atom[j] < 0) continue;   // ghosts and padding have no list of their own
+    const unsigned g = pair_hash((unsigned)i, (unsigned)j);
+    own += g;
+    atomicSub(acc + j, g);
+  }
+  for (int o = 32; o > 0; o >>= 1) own += __shfl_xor(own, o);
+  if (lane == 0 && own) atomicAdd(acc + i, own);
+}
+__global__ __launch_bounds__(256) void list_symmetry_verdict_kernel(const unsigned* __restrict__ acc, int ntotal, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ntotal && acc[i] != 0u) atomicOr(out, 1);
+}
+void launch_list_symmetry(const int* d_ilist, const int* d_nbr_off, const int* d_numneigh, const int* d_jraw, const int* d_row_of_atom,
+                          int nlocal, int ntotal, unsigned* d_acc, int* d_out, hipStream_t st) {
+  note_launch_error(hipMemsetAsync(d_acc, 0, sizeof(unsigned) * (size_t)(ntotal > 0 ? ntotal : 1), st));
+  note_launch_error(hipMemsetAsync(d_out, 0, sizeof(int), st));
+  if (nlocal <= 0) return;
+  hipLaunchKernelGGL(list_symmetry_kernel, dim3((nlocal + 3) / 4), dim3(256), 0, st, d_ilist, d_nbr_off, d_numneigh, d_jraw, d_row_of_atom,
+                     nlocal, ntotal, d_acc);
+  hipLaunchKernelGGL(list_symmetry_verdict_kernel, dim3((ntotal + 255) / 256), dim3(256), 0, st, d_acc, ntotal, d_out);
+}
+
 // ---- final reductions ------------------------------------------------------------------------------------
 // ONE launch: blocks [0, kFinishBlocks) sum the row energies (enough blocks that each walks its rows in a few dependent loads) and ADD their share to ev_out[0] (zeroed by pack_kernel;
 // a few double atomics on one address), block kFinishBlocks reduces the virial rows, the rest convert the force
