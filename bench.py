@@ -126,6 +126,47 @@ def aev_bytes_per_step(A, nlocal, ntotal, npairs):
     return fwd, bwd
 
 
+# ---- compute bound of the AEV passes ("useful work per centre") ---------------------------------------
+# Lane-operations (one FMA, multiply, add or compare of one lane) and transcendentals (exp / log / cos / sqrt / rcp) the
+# ALGORITHM needs, counted from SURVEY.md 8(a) rows a5 / a6 with nA x nZ = 8 x 4 angular and 16 radial terms:
+#   radial entry (neighbour inside Rcr), forward: distance 6 + cutoff 3 + 16 x (shift, square, scale, weight, add) ~ 45 ops;
+#       sqrt, cos, 16 exp = 18 transcendentals.  Backward: the same terms again + 16 x (weight with dE/dAEV, derivative) + the
+#       chain to the two atoms ~ 60 ops, 18 transcendentals.
+#   triple (pair of neighbours inside Rca), forward: dot product, cos(theta'), sin, 4 x (angle shift 2, power 2) + 8 x radial
+#       factor 3 + 32 products + 32 adds ~ 75 ops (FMA-fused); 1 sqrt + 4 x (log, exp) + 8 exp = 17 transcendentals.
+#       Backward: the factors again (43) + two 8x4 contractions with dE/dAEV and their derivatives (~100) + the chain rule to
+#       three atoms (~45) ~ 190 ops, 17 transcendentals.
+# Priced at the vector unit's measured issue rate: one wave64 fp32 instruction per 2.6 cycles and SIMD at saturation, a
+# transcendental 5x that (tools/issue_probe.hip, profiles/r03_issue_probe.log), 1024 SIMDs at the nominal 2.4 GHz.  The
+# datasheet's 157.3 TFLOP/s counts packed FMAs on every lane; the unpacked FMA rate behind this bound is 121 TFLOP/s.
+AEV_OPS = {"fwd": {"radial": (45, 18), "triple": (75, 17)}, "bwd": {"radial": (60, 18), "triple": (190, 17)}}
+VALU_CYCLES_PER_WAVE_INSTR = 2.6
+TRANSCENDENTAL_COST = 5.0
+
+
+def neighbour_statistics(inp, rcr, rca):
+    """(radial entries, angular neighbours, triples) summed over the owned atoms, from the positions and the list"""
+    import numpy as np
+    i = np.repeat(np.arange(inp.nlocal), inp.numneigh)
+    nr = np.zeros(inp.nlocal, dtype=np.int64)
+    na = np.zeros(inp.nlocal, dtype=np.int64)
+    step = 4_000_000
+    for a in range(0, i.shape[0], step):
+        ii, jj = i[a:a + step], inp.jlist[a:a + step]
+        d2 = ((inp.x[jj] - inp.x[ii]) ** 2).sum(1)
+        nr += np.bincount(ii[d2 < rcr * rcr], minlength=inp.nlocal)
+        na += np.bincount(ii[d2 < rca * rca], minlength=inp.nlocal)
+    return int(nr.sum()), int(na.sum()), int((na * (na - 1) // 2).sum())
+
+
+def aev_compute_bound_ms(which, n_radial, n_triples):
+    """time the useful work of one AEV pass would take at the vector unit's issue rate (see AEV_OPS)"""
+    (ro, rt), (to, tt) = AEV_OPS[which]["radial"], AEV_OPS[which]["triple"]
+    lane_ops = n_radial * (ro + TRANSCENDENTAL_COST * rt) + n_triples * (to + TRANSCENDENTAL_COST * tt)
+    wave_instr = lane_ops / 64.0
+    return wave_instr * VALU_CYCLES_PER_WAVE_INSTR / (1024 * 2.4e9) * 1e3
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -377,14 +418,15 @@ def main():
         dense_pass = {"ms_per_step": dtd / n2 * 1e3, "value": n2 / dtd * 0.0432,
                       "phase_ms": {k: phd[k] / max(phd["calls"], 1) for k in ("compact", "aev_fwd", "mlp", "aev_bwd")}}
         fl = mlp_flops_per_step(model, np.bincount(system.types - 1, minlength=model.num_species))
-        dense_pass["mlp_tflops"] = fl / (dense_pass["phase_ms"]["mlp"] * 1e-3) / 1e12
-        dense_pass["mlp_frac_of_f32_mfma_peak"] = dense_pass["mlp_tflops"] / PEAK_F32_MFMA_TFLOPS
+        dense_pass["mlp_algorithmic_fp32_tflops"] = fl / (dense_pass["phase_ms"]["mlp"] * 1e-3) / 1e12
+        dense_pass["mlp_frac_of_16bit_mfma_peak"] = 6.0 * dense_pass["mlp_algorithmic_fp32_tflops"] / PEAK_16BIT_MFMA_TFLOPS
         ani.set_option("prune_absent_species", 1)
     dt_hot, ph_hot = wl.timed_run(args.steps, args.warmup)
     energy_local = float(wl.d_ev[0].item())
     if not np.isfinite(energy_local) and not os.environ.get("ANI_BENCH_ALLOW_NAN"):   # the variable: timing-only ablation builds
         raise SystemExit("non-finite energy: LDS neighbour capacity exceeded or numerical failure")
     aev_cols = ani.debug_view().aev_active_length  # columns of the species present (1008 when all 7 occur)
+    mlp_kernel_name = ani.last_mlp_kernel()
 
     # ---- the MD loop: the headline -----------------------------------------------------------------------------------
     if args.no_md:
@@ -453,43 +495,56 @@ def main():
             n = counter(prefix, "SQ_INSTS_VALU")
             return n * 4.0 / (1024 * 2.4e9 * t_ms * 1e-3) if n and t_ms > 0 else None
 
+        # useful work of the AEV passes (this rank's share), for their compute bound
+        n_rad, n_ang, n_tri = neighbour_statistics(inp, *ani.cutoffs())
+        share = nl / max(inp.nlocal, 1)
+        n_rad, n_tri = n_rad * share, n_tri * share
+        aev_note = ("bound by the CUs' vector issue, not by HBM (DESIGN.md 3.1): `frac` is the HBM fraction SURVEY 8(d) asks for "
+                    "(algorithmic bytes / time / 8 TB/s); compute_bound_ms = the useful lane-operations and transcendentals of "
+                    "the pass (bench.py AEV_OPS: counts per radial entry and per triple x this structure's entries) at the "
+                    "vector unit's measured issue rate (2.6 cycles per wave64 instruction and SIMD, a transcendental 5x, "
+                    "1024 SIMDs, 2.4 GHz); compute_frac = compute_bound_ms / time; valu_frac_4cyc = SQ_INSTS_VALU x 4 cycles / "
+                    "(1024 SIMDs x time x 2.4 GHz): how busy the vector units are with the instructions the kernel executes")
+        cb_b, cb_f = aev_compute_bound_ms("bwd", n_rad, n_tri), aev_compute_bound_ms("fwd", n_rad, n_tri)
         bwd_roof = dict(bound="hbm", achieved=bb / (t_bwd * 1e-3) / 1e9 if t_bwd > 0 else None, peak=PEAK_HBM_GBS, unit="GB/s",
                         traffic=hbm_traffic("ani::aev_backward"), kernel="aev_backward_fast", ms_per_launch=t_bwd, bytes_per_launch=bb,
+                        compute_bound_ms=cb_b, compute_frac=cb_b / t_bwd if t_bwd > 0 else None,
                         valu_frac=valu("ani::aev_backward", t_bwd), valu_frac_4cyc=valu4("ani::aev_backward", t_bwd),
-                        note="bound by the CUs' vector issue (and, next, their LDS), not by HBM (DESIGN.md 3.1): ~1480 VALU "
-                             "wave-instructions per centre, a fifth of them transcendentals, DPP moves and half-wave swaps that hold "
-                             "the issue 3-5x as long as an FMA (tools/issue_probe.hip); valu_frac = SQ_INSTS_VALU x 2.4 cycles / "
-                             "(1024 SIMDs x time x 2.4 GHz), valu_frac_4cyc the same at 4 cycles per instruction",
-                        counters=pmc_note)
+                        radial_entries=n_rad, triples=n_tri, note=aev_note, counters=pmc_note)
         bwd_roof["frac"] = bwd_roof["achieved"] / PEAK_HBM_GBS if bwd_roof["achieved"] else None
         t_f = t_fwd + t_cmp
         fwd_roof = dict(bound="hbm", achieved=bf / (t_f * 1e-3) / 1e9 if t_f > 0 else None, peak=PEAK_HBM_GBS, unit="GB/s",
                         traffic=(hbm_traffic("ani::aev_forward") or 0) + (hbm_traffic("ani::nbr_compact") or 0) if pmc else None,
-                        kernel=("aev_forward_fused (neighbour compaction + AEV forward in one launch)" if t_cmp < 0.25 * t_fwd and t_cmp < 0.02
-                                else "nbr_compact_kernel + aev_forward_fast"), ms_per_launch=t_f, ms_compact=t_cmp, ms_forward=t_fwd,
-                        bytes_per_launch=bf, valu_frac=valu("ani::aev_forward", t_fwd), valu_frac_4cyc=valu4("ani::aev_forward", t_fwd))
+                        kernel=("aev_forward_fused" if t_cmp < 0.25 * t_fwd and t_cmp < 0.02 else "nbr_compact_kernel + aev_forward_fast"),
+                        kernel_note="neighbour compaction + AEV forward in one launch" if t_cmp < 0.25 * t_fwd and t_cmp < 0.02 else None,
+                        ms_per_launch=t_f, ms_compact=t_cmp, ms_forward=t_fwd, bytes_per_launch=bf,
+                        compute_bound_ms=cb_f, compute_frac=cb_f / t_f if t_f > 0 else None,
+                        valu_frac=valu("ani::aev_forward", t_fwd), valu_frac_4cyc=valu4("ani::aev_forward", t_fwd),
+                        radial_entries=n_rad, triples=n_tri, note=aev_note, counters=pmc_note)
         fwd_roof["frac"] = fwd_roof["achieved"] / PEAK_HBM_GBS if fwd_roof["achieved"] else None
-        # The MLP against the three things that can bound it.  The library default evaluates an fp32 product EXACTLY as six
-        # bf16 MFMA products (mlp_arith 1), so the matrix pipe it runs on is the 16-bit one and executes 6x the algorithmic flops.
+        # The MLP against its bound: the matrix pipe.  The library default evaluates an fp32 product EXACTLY as six bf16 MFMA
+        # products (mlp_arith 1), so the pipe it runs on is the 16-bit one and executes 6x the algorithmic flops:
+        # frac = products x algorithmic flops / time / 2.5 PFLOP/s.
         nprod = {0: 1, 1: 6, 2: 3}[md_info["mlp_arith"] if md_info else 1]
         mlp_tr = (hbm_traffic("ani::mlp_fused") or hbm_traffic("ani::mlp_pipeline") or hbm_traffic("ani::gemm_grouped") or
                   hbm_traffic("ani::mlp_chain"))
-        mlp_tf = flops / (t_mlp * 1e-3) / 1e12 if t_mlp > 0 else None
-        mlp_roof = dict(achieved=mlp_tf, unit="TFLOP/s", traffic=mlp_tr,
-                        kernel="MLP forward + backward of every species bucket and member (six products per member)",
-                        ms_per_step=t_mlp, flops_per_step=flops, flops_per_step_full_width_aev=flops_dense, aev_columns=aev_cols,
+        mlp_peak = PEAK_16BIT_MFMA_TFLOPS if nprod > 1 else PEAK_F32_MFMA_TFLOPS
+        mlp_exec_tf = flops * nprod / (t_mlp * 1e-3) / 1e12 if t_mlp > 0 else None
+        mlp_roof = dict(bound="mfma", achieved=mlp_exec_tf, peak=mlp_peak, unit="TFLOP/s", traffic=mlp_tr,
+                        kernel=mlp_kernel_name, ms_per_launch=t_mlp, flops_per_launch=flops * nprod,
+                        algorithmic_fp32_flops=flops, algorithmic_fp32_flops_full_width_aev=flops_dense, aev_columns=aev_cols,
                         mfma_products_per_fp32_product=nprod,
-                        frac_f32_equiv=mlp_tf / PEAK_F32_MFMA_TFLOPS if mlp_tf else None,
-                        frac_mfma_pipe=(mlp_tf * nprod / (PEAK_16BIT_MFMA_TFLOPS if nprod > 1 else PEAK_F32_MFMA_TFLOPS)) if mlp_tf else None,
-                        frac_hbm=(mlp_tr / (t_mlp * 1e-3) / 1e9 / PEAK_HBM_GBS) if (mlp_tr and t_mlp > 0) else None,
-                        note="frac_f32_equiv = algorithmic fp32 flops / time / the fp32-input MFMA peak (157.3 TF; SURVEY 8(d)'s "
-                             "accounting); frac_mfma_pipe = the MFMA flops actually executed (algorithmic x products per fp32 product) "
-                             "/ time / the dense peak of the pipe they run on (2.5 PF for the 16-bit splits); frac_hbm = counter "
-                             "traffic / time / 8 TB/s (null without a counter summary of these sources); `bound` names the largest")
-        cands = {"mfma": mlp_roof["frac_mfma_pipe"] or 0.0, "hbm": mlp_roof["frac_hbm"] or 0.0}
-        mlp_roof["bound"] = max(cands, key=cands.get)
-        mlp_roof["frac"] = cands[mlp_roof["bound"]]
-        mlp_roof["peak"] = PEAK_HBM_GBS if mlp_roof["bound"] == "hbm" else (PEAK_16BIT_MFMA_TFLOPS if nprod > 1 else PEAK_F32_MFMA_TFLOPS)
+                        algorithmic_fp32_tflops=flops / (t_mlp * 1e-3) / 1e12 if t_mlp > 0 else None,
+                        hbm_frac=(mlp_tr / (t_mlp * 1e-3) / 1e9 / PEAK_HBM_GBS) if (mlp_tr and t_mlp > 0) else None,
+                        note="MLP forward + backward of every species bucket and member in one launch; achieved = the MFMA flops "
+                             "executed (algorithmic fp32 flops 4 M sum_s n_s P_s over the AEV columns in use x MFMA products per fp32 "
+                             "product) / the launch's average duration; peak = the dense peak of the pipe they run on "
+                             "(/opt/skills/guides/MI355X_MICROARCH.md); hbm_frac = counter traffic / time / 8 TB/s",
+                        counters=pmc_note)
+        mlp_roof["frac"] = mlp_exec_tf / mlp_peak if mlp_exec_tf else None
+        # `roofline` is the kernel with the largest share of the step (row 1 of the rocprofv3 --stats summary of this command)
+        roofs = sorted([(t_mlp, mlp_roof), (t_bwd, bwd_roof), (t_f, fwd_roof)], key=lambda r: -r[0])
+        main_roof, other_roofs = roofs[0][1], [r[1] for r in roofs[1:]]
 
         what = "static positions, list reused (hot path only)" if args.no_md else \
             ("velocity Verlet + Langevin 300 K, dt 0.5 fs, skin 2.0, rebuild check every 10 steps, all on the device: the "
@@ -515,7 +570,7 @@ def main():
                        "prune_absent_species": not args.dense_aev, "aev_columns": aev_cols, "backend": backend if world > 1 else None,
                        "matom_steps_per_s": args.atoms * steps / dt / 1e6,
                        "vs_baseline_note": "published numbers are LAMMPS Performance lines on A100s (examples/benchmark/README.md:78-81): other hardware, same metric and workload"},
-            "roofline": bwd_roof, "roofline_other": [fwd_roof, mlp_roof], "full_width_aev_pass": dense_pass,
+            "roofline": main_roof, "roofline_other": other_roofs, "full_width_aev_pass": dense_pass,
             "phase_ms": {"nbr_compact": t_cmp, "aev_fwd": t_fwd, "mlp": t_mlp, "aev_bwd": t_bwd, "finish": t_other},
             "md_loop": md_info,
             "hot_path": {"what": "pair_style compute() alone: static positions, list reused (ago > 0), ghost-force exchange included",

@@ -196,6 +196,9 @@ typedef struct {
                                       atoms (informational: option aev_symmetric_radial was off for that epoch).  The device entry points cannot return these (nothing
                                       synchronises; the energy becomes NaN): a loop that finds a NaN energy reads this */
 } ani_debug_view;
+/* name of the kernel that ran the MLP of the last step ("mlp_fused<3>", "mlp_chain", "mlp_pipeline", "gemm_grouped ..."): what a
+ * profile's kernel statistics list it under (bench.py's roofline block names it) */
+const char* ani_last_mlp_kernel(const ani_handle* h);
 int ani_debug_get(ani_handle* h, ani_debug_view* out);
 /* out[c], c < aev_active_length: column of the model's full AEV that column c of d_aev holds */
 int ani_debug_colmap(ani_handle* h, int* out);

@@ -121,6 +121,7 @@ struct ani_handle {
   int aev_sym_radial = 1;        // ani_set_option("aev_symmetric_radial"): see AevArgs::row_of_atom
   int aev_tickets_min = 40000;   // ani_set_option("aev_tickets_min"): launches of fewer rows keep the fixed stride
   int mlp_fused_sched = 1;   // ani_set_option("mlp_fused_schedule"): 1 = static first-fit schedule of the fused launch, 0 = a counter
+  const char* last_mlp_kernel = "";   // ani_last_mlp_kernel: the kernel that ran the MLP of the last step
   int mlp_fused = 1;   // ani_set_option("mlp_fused"): 1 = networks of three hidden layers run as one launch, a 128-row tile per
                        // workgroup with the activations in registers (ani_kernels_mlpf.hip); 0 = the per-layer kernels
   int fused_mask[2] = {-2, -2};   // active_mask the fused streams of each arithmetic were built for
@@ -723,6 +724,7 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
     G.sched_blocks = bins;
   }
   HIP_TRY(h, launch_mlp_fused(G, arith, st));
+  h->last_mlp_kernel = arith == MLP_F16X2 ? "mlp_fused<2>" : "mlp_fused<3>";
   if (G.member_items) launch_sum_parts(h->gaev_parts.p, G.part_stride, m.M, h->gaev.p, (long long)h->nrows * ka, st);
   return ANI_OK;
 }
@@ -864,7 +866,9 @@ int compute_mlp(ani_handle* h, hipStream_t st) {
     for (const auto& lp : layer_probs) flat.insert(flat.end(), lp.begin(), lp.end());
     HIP_TRY(h, launch_mlp_chain(flat.data(), layer_epi.data(), (int)layer_probs.size(), np, &h->chain_plan, st, arith, pipeline,
                                 h->err_flag.p));
+    h->last_mlp_kernel = pipeline ? "mlp_pipeline" : "mlp_chain";
   } else {
+    h->last_mlp_kernel = "gemm_grouped (one launch per layer)";
     for (size_t l = 0; l < layer_probs.size(); l++)
       launch_gemm_group(layer_probs[l].data(), (int)layer_probs[l].size(), (Epilogue)layer_epi[l], st, arith);
   }
@@ -1607,6 +1611,8 @@ int ani_compute_half(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
   return ani_compute_full(h, ntotal, nlocal, species, coordinates, h->npairs, nullptr, nullptr, nullptr, ago, eflag_atom, vflag,
                           out_energy, out_force, out_atomic_energies, out_virial);
 }
+
+const char* ani_last_mlp_kernel(const ani_handle* h) { return h ? h->last_mlp_kernel : ""; }
 
 int ani_attach_comm(ani_handle* h, void* comm) {
   if (!h) return ANI_ERR_ARG;

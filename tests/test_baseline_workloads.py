@@ -8,8 +8,12 @@
     fp64 kernels at 1e-8), plus the "fp32 vs fp64 force tolerance sweep" the config names: the fp32 path against the
     fp64 kernels over gas densities from the reference's 0.25 g/cm3 up to 4x that.
 
-configs[2] (100 002 atoms) is covered by test_hip_properties.py::test_full_size_water_box_properties and, against the
-oracle, by every bench.py run (`parity` block); configs[3] and the 8-GPU part of configs[4] need an 8-GPU node.
+  * configs[2]: the 100 002-atom water box of the headline, 1 member, with the library's DEFAULT options — the paths that only
+    switch on at size (fused one-member MLP from ~16 000 atoms, rows by ticket from 40 000 rows, the static tile schedule,
+    symmetric radial collection, compaction inside the forward launch) — at `ago = 0` and on a moved `ago = 1` step; and the
+    per-GPU shares of configs[3] (12 501 / 25 002 / 50 001 atoms), which straddle both thresholds.
+
+configs[3] and the 8-GPU part of configs[4] need an 8-GPU node.
 Synthetic seeded weights (no trained weights in the container): parity here is HIP path == restatement.
 """
 import numpy as np
@@ -58,6 +62,38 @@ def test_config1_water_10k_8_members_against_oracle(model_cache, hip):
     ref2 = Oracle(p).compute(moved)
     got2 = ani.compute(moved, ago=1)
     _check(got2, ref2, inp.nlocal, F_TOL, E_TOL_PER_ATOM * inp.nlocal, 1.0)
+    ani.close()
+
+
+@pytest.mark.parametrize("natoms", [100002, 50001, 25002, 12501])
+def test_config2_water_box_default_paths_against_oracle(natoms, model_cache, hip):
+    """Tolerances: forces 2.3e-3 kcal/mol/A = 1e-4 eV/A (north star; models/test_models.py:213-214 uses 1e-3 relative /
+    absolute on fp32 forces), rms 3e-4, energy 1e-5 kcal/mol per atom (src/ani_csrc/test_model.cpp:164 allows 3e-4 Hartree on
+    30 atoms)."""
+    from oracle import Oracle
+    p = model_cache("ani2x", 1, 2024)
+    inp = hx.decompose(hx.spatial_sort(hx.water_box(natoms, seed=12345)))
+    o = Oracle(p)
+    ref = o.compute(inp)
+    ani = hip.ANI(p, 0, -1)          # default options: whatever the library picks at this size is what is checked
+    got = ani.compute(inp, ago=0)
+    v_tol = max(2.0, 2e-5 * float(np.abs(ref["virial"]).max()))    # fp32 sums over 1e5 atoms of terms of order 10
+    err = _check(got, ref, inp.nlocal, F_TOL, E_TOL_PER_ATOM * inp.nlocal, v_tol)
+    rms = float(np.sqrt((err ** 2).mean()))
+    kern = ani.last_mlp_kernel()
+    print(f"water-{natoms} x 1 [{kern}]: max |dF| {err.max():.2e}, rms {rms:.2e} kcal/mol/A, "
+          f"|dE| {abs(got['energy'] - ref['energy']):.2e} kcal/mol")
+    assert rms < 3e-4
+    if natoms >= 50001:
+        assert kern.startswith("mlp_fused"), kern   # the size-dependent choice this test is about
+    # a step between re-neighbourings: atoms moved, the cached list (and its buckets, tickets, schedule) reused
+    moved = hx.RankInput(**{**inp.__dict__, "x": inp.x + np.random.default_rng(1).normal(0, 0.02, size=inp.x.shape)})
+    moved.x[inp.nlocal:] = inp.x[inp.nlocal:] + (moved.x[inp.owner_lidx] - inp.x[inp.owner_lidx])
+    ref2 = o.compute(moved)
+    got2 = ani.compute(moved, ago=1)
+    err2 = _check(got2, ref2, inp.nlocal, F_TOL, E_TOL_PER_ATOM * inp.nlocal, v_tol)
+    assert float(np.sqrt((err2 ** 2).mean())) < 3e-4
+    assert np.abs(got2["force"] - got["force"]).max() > 1e-2      # it is another configuration
     ani.close()
 
 

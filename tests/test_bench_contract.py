@@ -23,9 +23,19 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["unit"] == "ns/day" and d["higher_is_better"] is True
     assert d["vs_baseline"] is None            # only the published 100 002-atom configuration has a baseline number
     assert "workload" in d["config"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu_frac"):
-        assert k in d["roofline"], k
-    assert d["roofline"]["bound"] in ("hbm", "mfma")
+    # `roofline` is the kernel with the largest share of the step, the other two follow in `roofline_other`
+    roofs = [d["roofline"]] + d["roofline_other"]
+    assert len(roofs) == 3 and d["roofline"]["ms_per_launch"] == max(r["ms_per_launch"] for r in roofs)
+    for r in roofs:
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "ms_per_launch"):
+            assert k in r, k
+        assert r["bound"] in ("hbm", "mfma")
+        if r["bound"] == "mfma":     # the MLP launch: MFMA flops executed / launch duration / the pipe's dense peak
+            assert abs(r["frac"] - r["flops_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e12 / r["peak"]) < 1e-9
+            assert r["kernel"].startswith(("mlp_", "gemm_grouped"))
+        else:                        # the AEV passes: the survey's HBM fraction, and the compute bound beside it
+            assert abs(r["frac"] - r["bytes_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e9 / r["peak"]) < 1e-9
+            assert 0.0 < r["compute_frac"] < 1.0 and "valu_frac" in r
     assert d["roofline"]["traffic"] is None     # PMC-derived numbers only for the profiled workload on unchanged kernel sources
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k

@@ -2,9 +2,10 @@
 # durations of the individual MLP launches of one step (rocprofv3 --kernel-trace), default bench workload
 # usage: tools/ktrace_mlp.sh TAG [bench args]
 TAG=${1:-m}; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -uo pipefail
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on a GPU box through gpurun (GRAFT_REPO_ROOT is unset)}" || exit 1
 OUT=gpurun_out/ktrace_$TAG
-rm -rf $OUT && mkdir -p $OUT
+rm -rf "$OUT" && mkdir -p "$OUT"
 timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT -o s --output-format csv -- python bench.py --no-cpu-baseline --no-dense-pass --no-extra --no-md --steps 20 --warmup 5 "$@" > $OUT/bench.json 2> $OUT/err.log
 python - "$(find $OUT -name '*kernel_trace.csv' | head -1)" <<'PY'
 import csv, sys, collections

@@ -1,10 +1,11 @@
 #!/bin/bash
 # PMC counters for the ani:: kernels of the default bench workload.  usage: tools/pmc.sh TAG "CTR1 CTR2 ..." ["CTR..." ...]
 # (each quoted group is one rocprofv3 pass, <= 8 SQ counters)
-TAG=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=${1:?usage: TAG [counter groups]}; shift
+set -uo pipefail
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on a GPU box through gpurun (GRAFT_REPO_ROOT is unset)}" || exit 1
 OUT=gpurun_out/pmc_$TAG
-rm -rf $OUT && mkdir -p $OUT
+rm -rf "$OUT" && mkdir -p "$OUT"
 ARGS="--no-cpu-baseline --no-dense-pass --no-extra --no-md --steps 20 --warmup 3"
 n=0
 for grp in "$@"; do

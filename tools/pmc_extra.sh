@@ -1,13 +1,14 @@
 #!/bin/bash
 # extra counter passes over the default hot path (instruction cache, MFMA busy cycles, wait classes); run on the GPU box:
 #   tools/pmc_extra.sh "CTR1 CTR2" ["CTR3 ..." ...]  -> gpurun_out/pmc_extra/<first counter>/...  + a per-kernel summary on stdout
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -uo pipefail
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on a GPU box through gpurun (GRAFT_REPO_ROOT is unset)}" || exit 1
 OUT=gpurun_out/pmc_extra
 mkdir -p $OUT
 ARGS="--no-cpu-baseline --no-dense-pass --no-extra --no-md --steps 20 --warmup 3"
 for c in "$@"; do
   tag=$(echo $c | cut -d' ' -f1)
-  rm -rf $OUT/$tag
+  rm -rf "${OUT:?}/$tag"
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $OUT/$tag -o p --output-format csv -- python bench.py $ARGS > /dev/null 2> $OUT/$tag.err
 done
 python - "$OUT" <<'PY'

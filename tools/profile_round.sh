@@ -5,9 +5,10 @@
 #     sources it was measured on (bench.py uses its numbers only while that digest still matches)
 # Run on the GPU box from the repo root:  tools/profile_round.sh [TAG]   -> gpurun_out/profile_TAG/
 TAG=${1:-r02}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -uo pipefail
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on a GPU box through gpurun (GRAFT_REPO_ROOT is unset)}" || exit 1
 OUT=gpurun_out/profile_$TAG
-rm -rf $OUT && mkdir -p $OUT
+rm -rf "$OUT" && mkdir -p "$OUT"
 ARGS="--no-cpu-baseline --no-dense-pass --no-extra --steps 40 --warmup 5"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE"; do
