@@ -303,12 +303,13 @@ def main():
         # several ranks over RCCL: the exchanges run inside libani_hip.so (include/ani_comm.h: grouped ncclSend / ncclRecv on
         # the compute stream); ANI_BENCH_NATIVE_COMM=0 keeps them on torch.distributed's all_to_all_single for comparison
         native, native_note = None, None
-        if world > 1 and backend == "nccl" and os.environ.get("ANI_BENCH_NATIVE_COMM", "1") not in ("", "0"):
+        want_native = os.environ.get("ANI_BENCH_NATIVE_COMM", "1")   # "try": attempt it whatever the backend (rehearsals)
+        if world > 1 and (backend == "nccl" or want_native == "try") and want_native not in ("", "0"):
             try:
-                native = ani_hip.NativeComm.from_torch(dev_index)
-            except Exception as exc:   # still RCCL, through torch.distributed; said so in the JSON line
+                native = ani_hip.NativeComm.from_torch(dev_index)   # every rank gets one, or every rank raises
+            except Exception as exc:   # the exchange then goes through torch.distributed; said so in the JSON line
                 native_note = f"ani_comm unavailable ({exc}); "
-            ok = torch.tensor([1.0 if native is not None else 0.0], device=dev)
+            ok = torch.tensor([1.0 if native is not None else 0.0], device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # all ranks or none
             if float(ok) == 0.0 and native is not None:
                 native.close()

@@ -1,7 +1,8 @@
 /*
  * ani_comm.h — ghost exchange between the ranks of a domain-decomposed run, on the device, over RCCL (xGMI), part of
  * libani_hip.so.  No torch, no MPI: plain pointers and sizes; RCCL itself is loaded on first use (dlopen of
- * librccl.so.1), so single-GPU users of the library do not need it installed.
+ * librccl.so.1), so single-GPU users of the library do not need it installed; environment ANI_COMM_DISABLE_RCCL=1 makes every
+ * entry point that needs RCCL fail as if the library were absent.
  *
  * What it replaces in the reference: the pair style sums ghost forces into their owners with LAMMPS' host-side
  * `comm->reverse_comm(this)` and its pack/unpack callbacks (src/pair_ani.cpp:197-201,461-484), after the forces have been

@@ -42,6 +42,11 @@ Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    // ANI_COMM_DISABLE_RCCL=1: behave as if librccl were absent (callers then take their other transport: LAMMPS' own reverse
+    // communication in the adapter, torch.distributed in the python loop) -- also how the fallback is rehearsed on one card
+    if (const char* off = getenv("ANI_COMM_DISABLE_RCCL")) {
+      if (off[0] && strcmp(off, "0") != 0) { r.err = "RCCL disabled by ANI_COMM_DISABLE_RCCL"; return; }
+    }
     const char* rocm = getenv("ROCM_PATH");
     const std::string fallbacks[] = {"librccl.so.1", std::string(rocm ? rocm : "/opt/rocm") + "/lib/librccl.so.1", "librccl.so"};
     for (const std::string& name : fallbacks) {

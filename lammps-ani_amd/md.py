@@ -38,7 +38,7 @@ class VerletRun:
     def __init__(self, ani, inp, box_len, device, dt: float = 0.5, cutoff: float = 5.1, skin: float = 2.0,
                  ghost_margin: float = 0.0, every: int = 10, masses=ANI2X_MASSES, group=None, seed: int = 12345,
                  langevin=None, box_lo=None, grid=None, periodic=(True, True, True), overlap=None, native_comm=None,
-                 force_collectives=False):
+                 force_collectives=False, vflag=False):
         """ani: ani_hip.ANI (full list, any precision); inp: harness.RankInput of this rank — only its OWNED atoms
         (positions, types, global tags) are taken, ghosts and lists are rebuilt here; langevin: None or
         (T_target, damp_fs) as ``fix langevin T T damp seed``; grid: processor grid (default comm.grid_for(world));
@@ -49,7 +49,8 @@ class VerletRun:
         latency-bound all-to-alls per step), off otherwise; environment ANI_MD_OVERLAP=0/1 overrides the default.
         native_comm: an ani_hip.NativeComm -- the exchanges then run inside libani_hip.so as grouped ncclSend / ncclRecv
         (include/ani_comm.h) instead of torch.distributed collectives; force_collectives: a single rank takes the several-rank
-        paths (one-participant collectives), so that one GPU can exercise them."""
+        paths (one-participant collectives), so that one GPU can exercise them.  vflag: every force evaluation also
+        accumulates the pair style's virial (``virial()``; LAMMPS sets vflag on thermo steps with a pressure compute)."""
         from .comm import DomainComm, grid_for
         self.ani, self.device, self.group = ani, device, group
         world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -60,6 +61,7 @@ class VerletRun:
         self.dc = DomainComm(grid or grid_for(world), box_lo, box_len, self.cutneigh, device, group=group, periodic=periodic,
                              native=native_comm, force_collectives=force_collectives)
         self.native = native_comm
+        self.vflag = bool(vflag)
         self.ex = self.dc   # the exchange object (forward_positions / reverse_add)
         self.masses = torch.as_tensor(np.asarray(masses, dtype=np.float64), device=device)
         self.langevin = langevin
@@ -169,7 +171,7 @@ class VerletRun:
         if not self._fused:
             self.f.zero_()
         self.ani.compute_device(self.ntotal, self.nlocal, None, self.x.data_ptr(), self.npairs, None, None, None, 1,
-                                self.f.data_ptr(), self.ev.data_ptr(), stream=self._stream)
+                                self.f.data_ptr(), self.ev.data_ptr(), vflag=self.vflag, stream=self._stream)
         if self._fused and not self.dc.multi:
             self._check(self._md.ani_md_reverse_ghosts(self.f.data_ptr(), self.dc.send_idx.data_ptr(), self.nlocal,
                                                        self.ntotal - self.nlocal, self._stream))
@@ -368,3 +370,21 @@ class VerletRun:
 
     def potential_energy(self) -> float:
         return self._allreduce_sum(self.ev[:1].clone())
+
+    def virial(self) -> np.ndarray:
+        """the pair style's virial of the last force evaluation, summed over ranks (kcal/mol, row-major 3x3; needs vflag)"""
+        if not self.vflag:
+            raise RuntimeError("VerletRun was made without vflag")
+        w = self.ev[1:10].clone()
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            if dist.get_backend(self.group) == "gloo" and w.is_cuda:
+                c = w.cpu()
+                dist.all_reduce(c, group=self.group)
+                w = c
+            else:
+                dist.all_reduce(w, group=self.group)
+        return w.cpu().numpy().reshape(3, 3)
+
+    def temperature(self, natoms_all: int) -> float:
+        """LAMMPS compute temp: 2 KE / ((3 N - 3) k_B)"""
+        return 2.0 * self.kinetic_energy() / ((3.0 * natoms_all - 3.0) * BOLTZ)

@@ -53,3 +53,32 @@ def test_relay_prints_only_the_json_line_and_passes_the_exit_code(tmp_path):
         assert "--nproc-per-node=4" in argv and "--nnodes=1" in argv
         assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
         assert argv[-4:] == ["--gpus", "4", "--steps", "7"] and argv[-5].endswith("bench.py")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_on_one_card_takes_the_fallback_transport():
+    """First-contact rehearsal of `bench.py --gpus N` on the one card a GPU box has: the parent launches two ranks (before it
+    touches the GPU), they meet over gloo (RCCL refuses two ranks on one device), try the native communicator, find RCCL
+    disabled, agree on that, and fall back to torch.distributed for the ghost exchange -- the sequence a node with a broken
+    librccl would take.  The JSON line must keep the driver's contract for N ranks."""
+    r = _run(["--gpus", "2", "--atoms", "6000", "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-dense-pass", "--no-extra"],
+             {"ANI_BENCH_BACKEND": "gloo", "ANI_BENCH_NATIVE_COMM": "try", "ANI_COMM_DISABLE_RCCL": "1",
+              "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["steps"] == 12 and d["warmup"] == 3
+    assert d["scaling"] == "strong" and d["unit"] == "ns/day" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["grid"] == [2, 1, 1] and d["config"]["backend"] == "gloo"
+    assert d["config"]["nlocal_rank0"] < 6000 and d["config"]["nghost_rank0"] > 0      # rank 0 holds a brick, not the box
+    ex = d["md_loop"]["exchange"]
+    assert "ani_comm unavailable" in ex and "ANI_COMM_DISABLE_RCCL" in ex and "torch.distributed all_to_all_single (gloo)" in ex
+    assert d["md_loop"]["energy_finite"] and d["md_loop"]["steps"] == 12
+    assert abs(d["value"] - 0.0432 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in d["roofline"], k
+    assert "cpu_baseline" not in d          # rank 0 at N = 1 only
