@@ -101,7 +101,7 @@ struct SpeciesNet {
     float* consts = nullptr;
     long long ppm = 0;   // pieces per member
     int cpm = 0;         // constants (floats) per member
-  } fu[2];
+  } fu[4];   // [arithmetic + 2 * generation]: generation 0 = the 32-rows-per-wave kernel's stream order, 1 = the 16-row kernel's
   int fused_shape = -1;
 };
 inline MlpArith planes_arith(int i) { return i == 0 ? MLP_BF16X3 : MLP_F16X2; }
@@ -124,7 +124,9 @@ struct ani_handle {
   const char* last_mlp_kernel = "";   // ani_last_mlp_kernel: the kernel that ran the MLP of the last step
   int mlp_fused = 1;   // ani_set_option("mlp_fused"): 1 = networks of three hidden layers run as one launch, a 128-row tile per
                        // workgroup with the activations in registers (ani_kernels_mlpf.hip); 0 = the per-layer kernels
-  int fused_mask[2] = {-2, -2};   // active_mask the fused streams of each arithmetic were built for
+  int fused_mask[4] = {-2, -2, -2, -2};   // active_mask the fused streams of each (arithmetic, generation) were built for
+  int mlp_fused_gen = 1;    // ani_set_option("mlp_fused_gen"): 1 = sixteen rows per wave (ani_kernels_mlpg.hip), 0 = thirty-two (mlpf)
+  int mlp_fused_rows = 0;   // ani_set_option("mlp_fused_rows"): rows per workgroup of the 16-row kernel: 128, 64, 0 = by size
   DevBuf<int> fused_counter;
   DevBuf<int> fused_sched;    // static schedule of the fused launch: items, then offsets (fused_schedule); remade per list epoch
   int sched_key[4] = {-1, -1, -1, -1};   // what it was made for: total tiles, items per tile, problems, bins
@@ -557,7 +559,7 @@ bool fused_eligible(const ani_handle* h) {
   // Small systems: a fused tile takes ~0.1 ms whatever else happens, so with fewer tiles than CUs the kernel costs that much
   // however few rows there are, while the chained per-layer launch of small systems scales down with them (MLP, exact
   // arithmetic: 12 501 atoms 0.09 fused against 0.08 chained; 25 002 atoms 0.09 against 0.12): fused from ~16 000 atoms on.
-  if (h->mlp_fused < 2 && m.M == 1) {   // (several members: the fused kernel's (tile, member) work items win at every size measured)
+  if (h->mlp_fused < 2 && m.M == 1 && !h->mlp_fused_gen) {   // (several members: the fused kernel's (tile, member) work items win at every size measured)
     int tiles = 0;
     for (int s = 0; s < m.S; s++) tiles += round_up(h->count[s], kRowTile) / kRowTile;
     if (tiles < 125) return false;
@@ -569,20 +571,20 @@ bool fused_eligible(const ani_handle* h) {
   return true;
 }
 
-void free_fused(ani_handle* h, int pi) {
+void free_fused(ani_handle* h, int fi) {
   for (auto& n : h->nets) {
-    if (n.fu[pi].stream) (void)hipFree(n.fu[pi].stream);
-    if (n.fu[pi].consts) (void)hipFree(n.fu[pi].consts);
-    n.fu[pi] = SpeciesNet::Fused{};
+    if (n.fu[fi].stream) (void)hipFree(n.fu[fi].stream);
+    if (n.fu[fi].consts) (void)hipFree(n.fu[fi].consts);
+    n.fu[fi] = SpeciesNet::Fused{};
   }
-  h->fused_mask[pi] = -2;
+  h->fused_mask[fi] = -2;
 }
 
 // weight streams + constants of every species for arithmetic `arith`, in the AEV layout of this epoch
-int ensure_fused(ani_handle* h, MlpArith arith, hipStream_t st) {
-  const int pi = arith == MLP_F16X2 ? 1 : 0, P = mlp_planes(arith);
-  if (h->fused_mask[pi] == h->active_mask) return ANI_OK;
-  free_fused(h, pi);
+int ensure_fused(ani_handle* h, MlpArith arith, int gen, hipStream_t st) {
+  const int pi = arith == MLP_F16X2 ? 1 : 0, P = mlp_planes(arith), fi = pi + 2 * gen;
+  if (h->fused_mask[fi] == h->active_mask) return ANI_OK;
+  free_fused(h, fi);
   const HostModel& m = h->model;
   const int M = m.M, acols = h->ap_run.aev_len, ka = h->ap_run.aev_stride;
   const int ks0 = acols / 16, nt0 = (acols + 31) / 32;
@@ -593,25 +595,44 @@ int ensure_fused(ani_handle* h, MlpArith arith, hipStream_t st) {
     n.fused_shape = shape;
     int nt[3];
     fused_shape_tiles(shape, nt);
-    SpeciesNet::Fused& f = n.fu[pi];
-    f.ppm = fused_pieces_per_member(shape, acols, P);
+    SpeciesNet::Fused& f = n.fu[fi];
+    f.ppm = gen ? fused16_pieces_per_member(shape, acols, P) : fused_pieces_per_member(shape, acols, P);
     f.cpm = fused_consts_floats(shape);
     HIP_TRY(h, hipMalloc((void**)&f.stream, (size_t)f.ppm * M * 1024));
     HIP_TRY(h, hipMalloc((void**)&f.consts, sizeof(float) * (size_t)f.cpm * M));
     std::vector<float> cst((size_t)f.cpm * M, 0.f);
     for (int a = 0; a < M; a++) {
       unsigned short* dst = reinterpret_cast<unsigned short*>(f.stream + (size_t)a * f.ppm * 1024);
-      auto emit = [&](const float* src, int ld, int rows, int kval, int NT, int KS, int chunk, float scale) {
-        launch_build_stream(src, ld, rows, kval, NT, KS, chunk, P, scale, dst, st);
-        dst += (size_t)NT * KS * P * 512;
-      };
       const float ws0 = n.wscale[0], ws1 = n.wscale[1], ws2 = n.wscale[2];
-      emit((n.W0c ? n.W0c : n.W[0]) + (size_t)a * d[1] * ka, ka, d[1], acols, nt[0], ks0, 0, ws0);                 // F1
-      emit(n.W[1] + (size_t)a * d[2] * n.w[1], n.w[1], d[2], d[1], nt[1], 2 * nt[0], 0, ws1);                       // F2
-      emit(n.W[2] + (size_t)a * d[3] * n.w[2], n.w[2], d[3], d[2], nt[2], 2 * nt[1], 0, ws2);                       // F3
-      emit(n.WT[2] + (size_t)a * d[2] * n.w[3], n.w[3], d[2], d[3], nt[1], 2 * nt[2], -1, ws2);                     // B3
-      emit(n.WT[1] + (size_t)a * d[1] * n.w[2], n.w[2], d[1], d[2], nt[0], 2 * nt[1], -1, ws1);                     // B2
-      emit((n.WT0c ? n.WT0c : n.WT[0]) + (size_t)a * n.w[1], M * n.w[1], acols, d[1], nt0, 2 * nt[0], 4, ws0);      // B1 (chunks of kChunk tiles)
+      if (!gen) {
+        auto emit = [&](const float* src, int ld, int rows, int kval, int NT, int KS, int chunk, float scale) {
+          launch_build_stream(src, ld, rows, kval, NT, KS, chunk, P, scale, dst, st);
+          dst += (size_t)NT * KS * P * 512;
+        };
+        emit((n.W0c ? n.W0c : n.W[0]) + (size_t)a * d[1] * ka, ka, d[1], acols, nt[0], ks0, 0, ws0);                 // F1
+        emit(n.W[1] + (size_t)a * d[2] * n.w[1], n.w[1], d[2], d[1], nt[1], 2 * nt[0], 0, ws1);                       // F2
+        emit(n.W[2] + (size_t)a * d[3] * n.w[2], n.w[2], d[3], d[2], nt[2], 2 * nt[1], 0, ws2);                       // F3
+        emit(n.WT[2] + (size_t)a * d[2] * n.w[3], n.w[3], d[2], d[3], nt[1], 2 * nt[2], -1, ws2);                     // B3
+        emit(n.WT[1] + (size_t)a * d[1] * n.w[2], n.w[2], d[1], d[2], nt[0], 2 * nt[1], -1, ws1);                     // B2
+        emit((n.WT0c ? n.WT0c : n.WT[0]) + (size_t)a * n.w[1], M * n.w[1], acols, d[1], nt0, 2 * nt[0], 4, ws0);      // B1 (chunks of kChunk tiles)
+      } else {
+        // the 16-row kernel's order (ani_kernels_mlpg.hip): 16-feature output tiles, 32-deep k-steps
+        const int n1 = 2 * nt[0], n2 = 2 * nt[1], n3 = 2 * nt[2], ks1 = (acols + 31) / 32, nt16 = (acols + 15) / 16;
+        auto emit = [&](const float* src, int ld, int rows, int kval, int NT, int KS, int order, int nt_off, int identity, float scale) {
+          launch_build_stream16(src, ld, rows, kval, NT, KS, order, nt_off, identity, P, scale, dst, st);
+          dst += (size_t)NT * KS * P * 512;
+        };
+        emit((n.W0c ? n.W0c : n.W[0]) + (size_t)a * d[1] * ka, ka, d[1], acols, n1, ks1, 0, 0, 1, ws0);               // F1: a slab per k-step
+        emit(n.W[1] + (size_t)a * d[2] * n.w[1], n.w[1], d[2], d[1], n2, n1 / 2, 0, 0, 0, ws1);                       // F2
+        emit(n.W[2] + (size_t)a * d[3] * n.w[2], n.w[2], d[3], d[2], n3, n2 / 2, 0, 0, 0, ws2);                       // F3
+        emit(n.WT[2] + (size_t)a * d[2] * n.w[3], n.w[3], d[2], d[3], n2, n3 / 2, 1, 0, 0, ws2);                      // B3: tile-major
+        emit(n.WT[1] + (size_t)a * d[1] * n.w[2], n.w[2], d[1], d[2], n1, n2 / 2, 1, 0, 0, ws1);                      // B2
+        for (int ci = 0, c0 = 0; ci < fused16_b1_chunks(nt16); ci++) {                                                // B1: chunks of tiles
+          const int ntc = fused16_b1_chunk_tiles(nt16, ci);
+          emit((n.WT0c ? n.WT0c : n.WT[0]) + (size_t)a * n.w[1], M * n.w[1], acols, d[1], ntc, n1 / 2, 0, c0, 0, ws0);
+          c0 += ntc;
+        }
+      }
       if ((size_t)(dst - reinterpret_cast<unsigned short*>(f.stream + (size_t)a * f.ppm * 1024)) != (size_t)f.ppm * 512) {
         h->err = "internal: fused MLP stream size mismatch";
         return ANI_ERR_MODEL;
@@ -639,16 +660,27 @@ int ensure_fused(ani_handle* h, MlpArith arith, hipStream_t st) {
     HIP_TRY(h, hipStreamSynchronize(st));   // cst is a local
   }
   HIP_TRY(h, hipGetLastError());
-  h->fused_mask[pi] = h->active_mask;
+  h->fused_mask[fi] = h->active_mask;
   return ANI_OK;
 }
 
 int compute_mlp_fused(ani_handle* h, hipStream_t st) {
   const HostModel& m = h->model;
   const MlpArith arith = h->mlp_arith;
-  const int pi = arith == MLP_F16X2 ? 1 : 0;
-  int rc = ensure_fused(h, arith, st);
+  const int gen = h->mlp_fused_gen ? 1 : 0, pi = (arith == MLP_F16X2 ? 1 : 0) + 2 * gen;
+  int rc = ensure_fused(h, arith, gen, st);
   if (rc) return rc;
+  // The 16-row kernel: 128-row tiles on eight waves (two per SIMD) where that fills the CUs, else 64-row tiles on four -- twice
+  // the workgroups, about half the latency of a tile (a decomposed box's per-GPU share: 12 501 water atoms are 99 tiles of 128).
+  int sub = 1;   // 64-row tiles per 128-row tile
+  if (gen) {
+    int tiles128 = 0;
+    for (int s = 0; s < m.S; s++) tiles128 += round_up(h->count[s], kRowTile) / kRowTile;
+    const int items128 = tiles128 * (m.M > 1 && h->mlp_fused != 3 ? m.M : 1);
+    // 64-row tiles only where they still fit one round (a tile of either form costs about the same time per row)
+    const bool small = h->mlp_fused_rows == 64 || (h->mlp_fused_rows == 0 && 2 * items128 <= fused_num_cus() + fused_num_cus() / 8);
+    sub = small ? 2 : 1;
+  }
   HIP_TRY(h, h->fused_counter.reserve(1));
   FusedArgs G{};
   G.M = m.M; G.alpha = (float)m.alpha; G.inv_alpha = (float)(1.0 / m.alpha); G.scale = 1.f / (float)m.M;
@@ -669,7 +701,7 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
       p.centre_of_row = h->centre_of_row.p + h->row_start[s];
       p.stream = n.fu[pi].stream; p.consts = n.fu[pi].consts;
       p.sE = h->nrows;
-      p.tiles = round_up(h->count[s], kRowTile) / kRowTile;
+      p.tiles = sub * (round_up(h->count[s], kRowTile) / kRowTile);
       p.shape = shape;
       p.ks0 = acols / 16; p.nt0 = (acols + 31) / 32; p.acols = acols; p.aev_stride = ka;
       p.pieces_per_member = (int)n.fu[pi].ppm; p.consts_per_member = n.fu[pi].cpm;
@@ -698,6 +730,7 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
     const int nitems = total * per_tile;
     int mix = np;   // the tile counts and shapes of the problems, folded into one word
     for (int q = 0; q < np; q++) mix = mix * 1000003 + G.p[q].tiles * 4 + G.p[q].shape;
+    mix = mix * 31 + sub + 2 * gen;
     if (h->sched_key[0] != total || h->sched_key[1] != per_tile || h->sched_key[2] != mix || h->sched_key[3] != bins || !h->fused_sched.p) {
       // item types: one per problem; a (tile, member) item costs what its tile's member costs.  Item t of the kernel's numbering
       // is tile t / per_tile: the items of a problem are contiguous.
@@ -723,8 +756,13 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
     G.sched_off = h->fused_sched.p + nitems;
     G.sched_blocks = bins;
   }
-  HIP_TRY(h, launch_mlp_fused(G, arith, st));
-  h->last_mlp_kernel = arith == MLP_F16X2 ? "mlp_fused<2>" : "mlp_fused<3>";
+  if (gen) {
+    HIP_TRY(h, launch_mlp_fused16(G, arith, sub == 2 ? 4 : 8, st));
+    h->last_mlp_kernel = arith == MLP_F16X2 ? (sub == 2 ? "mlp_fused16<2, 4>" : "mlp_fused16<2, 8>") : (sub == 2 ? "mlp_fused16<3, 4>" : "mlp_fused16<3, 8>");
+  } else {
+    HIP_TRY(h, launch_mlp_fused(G, arith, st));
+    h->last_mlp_kernel = arith == MLP_F16X2 ? "mlp_fused<2>" : "mlp_fused<3>";
+  }
   if (G.member_items) launch_sum_parts(h->gaev_parts.p, G.part_stride, m.M, h->gaev.p, (long long)h->nrows * ka, st);
   return ANI_OK;
 }
@@ -1277,7 +1315,7 @@ void ani_destroy(ani_handle* h) {
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
   h->virial_acc.release(); h->aev.release(); h->gaev.release(); h->act.release(); h->aev64.release(); h->gaev64.release(); h->act64.release(); h->e_rows64.release(); h->fbuf64.release(); h->e_rows.release(); h->fbuf.release();
-  free_fused(h, 0); free_fused(h, 1);
+  for (int fi = 0; fi < 4; fi++) free_fused(h, fi);
   h->fused_counter.release(); h->gaev_parts.release(); h->fused_sched.release();
   free_chain_plan(h->chain_plan);
   for (auto& e : h->evt_pool) if (e) (void)hipEventDestroy(e);
@@ -1679,6 +1717,18 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   }
   if (strcmp(name, "aev_fused") == 0) {
     h->aev_fused = value != 0;
+    return ANI_OK;
+  }
+  if (strcmp(name, "mlp_fused_gen") == 0) {
+    if (value < 0 || value > 1) { h->err = "mlp_fused_gen must be 0 or 1"; return ANI_ERR_ARG; }
+    h->mlp_fused_gen = value;
+    h->sched_key[0] = -1;
+    return ANI_OK;
+  }
+  if (strcmp(name, "mlp_fused_rows") == 0) {
+    if (value != 0 && value != 64 && value != 128) { h->err = "mlp_fused_rows must be 0, 64 or 128"; return ANI_ERR_ARG; }
+    h->mlp_fused_rows = value;
+    h->sched_key[0] = -1;
     return ANI_OK;
   }
   if (strcmp(name, "mlp_fused_schedule") == 0) {

@@ -131,6 +131,18 @@ long long fused_pieces_per_member(int shape, int acols, int P);
 void launch_build_stream(const float* src, int ld, int rows_valid, int k_valid, int NT, int KS, int chunk, int P, float scale,
                          unsigned short* dst, hipStream_t st);
 hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st);
+// The sixteen-rows-per-wave form of the same kernel (ani_kernels_mlpg.hip): waves = 8 takes the 128-row tiles of FusedArgs as
+// they are (two waves per SIMD), waves = 4 reads FusedProb::tiles / tile_start in 64-row tiles (one wave per SIMD, for launches
+// that would leave CUs idle).  Its weight stream has its own order (launch_build_stream16, fused16_pieces_per_member); the
+// constants block is the 32-row kernel's.  FusedProb::ks0 / nt0 are not used (derived from acols).
+hipError_t launch_mlp_fused16(const FusedArgs& G, MlpArith arith, int waves, hipStream_t st);
+long long fused16_pieces_per_member(int shape, int acols, int P);
+int fused16_b1_chunks(int nt0);                 // dE/dAEV chunks of nt0 16-column tiles ...
+int fused16_b1_chunk_tiles(int nt0, int ci);    // ... and the tiles of chunk ci (16, then 8, then the rest)
+// NT x KS blocks (16-row output tiles from tile nt_off on, 32-deep k-steps) of src[row][k]; order 0: k-step-major, 1: tile-major;
+// identity: k-slots in column order (the AEV operand of the first product) instead of the accumulator order
+void launch_build_stream16(const float* src, int ld, int rows_valid, int k_valid, int NT, int KS, int order, int nt_off, int identity,
+                           int P, float scale, unsigned short* dst, hipStream_t st);
 int fused_num_cus();
 // Static schedule of a launch: `nitem_types` kinds of work items (type j: count[j] items of relative cost[j], items numbered
 // type after type), `bins` workgroups.  Multifit: the smallest makespan T for which first-fit-decreasing packs every item into
