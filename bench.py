@@ -167,6 +167,61 @@ def aev_compute_bound_ms(which, n_radial, n_triples):
     return wave_instr * VALU_CYCLES_PER_WAVE_INSTR / (1024 * 2.4e9) * 1e3
 
 
+def adapter_path(inp, model_path, nsteps=40, every=20):
+    """The path LAMMPS itself calls, timed: tests/mock_lammps (a stand-in for LAMMPS' Atom / Neighbor / Comm objects) ->
+    PairANI::compute (lammps-ani_amd/csrc/pair_ani.cpp) -> ani_compute_full with HOST pointers -> forces back in atom->f.
+    Persistent arrays, eflag = vflag = 0, a re-neighbouring call every `every` steps; only compute() is timed
+    (tests/mock_lammps/driver.cpp mock_md_loop).  Two list sources: the flattened LAMMPS list and the device-built list."""
+    import ctypes as C
+    import numpy as np
+    mock_dir = os.path.join(ROOT, "tests", "mock_lammps")
+    so = os.path.join(mock_dir, "libpair_ani_mock.so")
+    try:
+        subprocess.run(["make", "-C", mock_dir, "-s"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        pass
+    if not os.path.exists(so):
+        return {"error": "tests/mock_lammps/libpair_ani_mock.so is missing"}
+    lib = C.CDLL(so)
+    lib.mock_create.restype = C.c_void_p
+    lib.mock_create.argtypes = [C.c_char_p, C.c_int]
+    lib.mock_error.restype = C.c_char_p
+    lib.mock_error.argtypes = [C.c_void_p]
+    lib.mock_pair_style.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_int]
+    lib.mock_compute.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+    lib.mock_md_loop.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.mock_destroy.argtypes = [C.c_void_p]
+    nt = inp.ntotal
+    x = np.ascontiguousarray(inp.x)
+    ty = np.ascontiguousarray(inp.types, dtype=np.int32)
+    nn = np.ascontiguousarray(inp.numneigh, dtype=np.int32)
+    jl = np.ascontiguousarray(inp.jlist, dtype=np.int32)
+    ow = np.ascontiguousarray(inp.owner_lidx, dtype=np.int32)
+    out = {"what": "PairANI::compute through the mock LAMMPS objects, host-pointer entry points (what `pair_style ani` costs per step "
+                   "before LAMMPS' own integrate / comm / neighbour work); eflag = vflag = 0",
+           "steps": nsteps, "reneighbour_every": every}
+    for source in ("hostlist", "devlist"):
+        h = lib.mock_create(b"real", 0)
+        args = ["5.1", model_path, "hip", "-1", "cuaev", "full", "single", source]
+        arr = (C.c_char_p * len(args))(*[a.encode() for a in args])
+        if lib.mock_pair_style(h, len(args), arr, 7) != 0:
+            out[source] = {"error": lib.mock_error(h).decode()}
+            continue
+        f = np.zeros((nt, 3)); e = np.zeros(1); v = np.zeros(6)
+        rc = lib.mock_compute(h, inp.nlocal, inp.nghost, x.ctypes.data, ty.ctypes.data, nn.ctypes.data, jl.ctypes.data, ow.ctypes.data,
+                              0, 1, 0, f.ctypes.data, e.ctypes.data, v.ctypes.data, None)
+        ms = np.zeros(3)
+        if rc == 0:
+            rc = lib.mock_md_loop(h, 10, every, ms.ctypes.data)        # warm-up (registrations, first-use costs)
+        if rc == 0:
+            rc = lib.mock_md_loop(h, nsteps, every, ms.ctypes.data)
+        out[source] = {"plain_ms_per_step": float(ms[0]), "reneighbour_ms_per_step": float(ms[1]),
+                       "ns_per_day_plain": 0.0432 / (float(ms[0]) * 1e-3) if ms[0] > 0 else None} if rc == 0 else \
+            {"error": lib.mock_error(h).decode()}
+        lib.mock_destroy(h)
+    return out
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -617,6 +672,8 @@ def main():
                     "max_abs_force_diff_to_default_path": float(np.abs(f32[: inp.nlocal] - f[: inp.nlocal]).max()),
                     "mlp_ms_per_step": ph32["mlp"] / max(ph32["calls"], 1)}
             ani.set_option("mlp_arith", 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["adapter_path"] = adapter_path(inp, wl.mpath)
     wl.close()
     if rank == 0 and world == 1 and not args.no_md and not args.no_extra:
         # labelled secondary: the same MD loop with the reduced-precision opt-in (two-term fp16 splits, three MFMA products)

@@ -196,6 +196,18 @@ typedef struct {
                                       atoms (informational: option aev_symmetric_radial was off for that epoch).  The device entry points cannot return these (nothing
                                       synchronises; the energy becomes NaN): a loop that finds a NaN energy reads this */
 } ani_debug_view;
+/*
+ * Page-lock / release a caller's host array (hipHostRegister / hipHostUnregister), so that the per-step copies of the host
+ * entry points from and to it are direct DMA transfers instead of the runtime's staged pageable copies (the reference copies
+ * pageable every step, src/ani_csrc/ani.cpp:206-209,250-251).  Explicit, not automatic: a registration belongs to an ADDRESS
+ * RANGE, and a range that is freed while registered and handed out again by the allocator would be transferred from stale
+ * pages -- release before the memory is freed or reallocated.  The LAMMPS adapter registers its own out_force buffer and, per
+ * neighbour-list epoch, the atom->x block (csrc/pair_ani.cpp).  Return ANI_ERR_DEVICE when the runtime refuses (overlap with
+ * another registration, limits): the copies then stay pageable, nothing else changes.
+ */
+int ani_host_register(const void* p, size_t bytes);
+int ani_host_unregister(const void* p);
+
 /* name of the kernel that ran the MLP of the last step ("mlp_fused<3>", "mlp_chain", "mlp_pipeline", "gemm_grouped ..."): what a
  * profile's kernel statistics list it under (bench.py's roofline block names it) */
 const char* ani_last_mlp_kernel(const ani_handle* h);

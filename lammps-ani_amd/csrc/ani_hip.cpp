@@ -1650,6 +1650,19 @@ int ani_compute_half(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
                           out_energy, out_force, out_atomic_energies, out_virial);
 }
 
+// Page-locking of caller arrays for the host entry points: explicit, because a registration belongs to an address range and
+// only the owner of the memory knows when that range stops meaning the same pages.
+int ani_host_register(const void* p, size_t bytes) {
+  if (!p || bytes == 0) return ANI_ERR_ARG;
+  if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return ANI_ERR_DEVICE; }
+  return ANI_OK;
+}
+int ani_host_unregister(const void* p) {
+  if (!p) return ANI_ERR_ARG;
+  if (hipHostUnregister(const_cast<void*>(p)) != hipSuccess) { (void)hipGetLastError(); return ANI_ERR_DEVICE; }
+  return ANI_OK;
+}
+
 const char* ani_last_mlp_kernel(const ani_handle* h) { return h ? h->last_mlp_kernel : ""; }
 
 int ani_attach_comm(ani_handle* h, void* comm) {

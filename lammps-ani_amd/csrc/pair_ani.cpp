@@ -58,8 +58,27 @@ PairANI::~PairANI() {
     memory->destroy(setflag);
     memory->destroy(cutsq);
   }
+  release_pins();
+  free(out_force);
   if (ani) ani_destroy(ani);
   if (acomm) ani_comm_destroy(acomm);
+}
+
+// host arrays page-locked for the per-step copies (include/ani_hip.h ani_host_register): released before the memory behind them
+// can change hands
+void PairANI::release_pins() {
+  if (x_registered) { ani_host_unregister(x_registered); x_registered = nullptr; }
+  if (out_force_pinned) { ani_host_unregister(out_force); out_force_pinned = false; }
+}
+
+void PairANI::grow_out_force(size_t doubles) {
+  if (doubles <= out_force_cap && out_force) return;
+  if (out_force_pinned) { ani_host_unregister(out_force); out_force_pinned = false; }
+  free(out_force);
+  out_force_cap = doubles + doubles / 2 + 64;   // grown 1.5x like the reference's arrays (src/pair_ani.cpp:119-127)
+  out_force = static_cast<double*>(malloc(out_force_cap * sizeof(double)));
+  if (!out_force) error->one(FLERR, "Pair ani: out of memory");
+  if (pin_host) out_force_pinned = ani_host_register(out_force, out_force_cap * sizeof(double)) == ANI_OK;
 }
 
 void PairANI::allocate() {
@@ -167,6 +186,9 @@ void PairANI::coeff(int narg, char** arg) {
 
 void PairANI::init_style() {
   if (!ani) error->all(FLERR, "Pair ani: no model loaded");
+  release_pins();   // a new run: whatever was page-locked for the last one may have been reallocated since
+  if (const char* e = getenv("LAMMPS_ANI_NO_PIN")) pin_host = !(e[0] && strcmp(e, "0") != 0);
+  if (!pin_host) { free(out_force); out_force = nullptr; out_force_cap = 0; }
   if (force->newton_pair == 1) {
     if (use_fullnbr) error->all(FLERR, "Pair style ANI requires newton pair off when using full neighbor list");
     error->all(FLERR, "Pair style ANI requires newton pair off when using half neighbor list");
@@ -195,6 +217,8 @@ void PairANI::compute(int eflag, int vflag) {
   const int ntotal = nlocal + atom->nghost;
   const int ago = neighbor->ago;
   const int inum = use_devlist ? nlocal : list->inum;
+  // LAMMPS may have reallocated atom->x while re-neighbouring: the old block's registration goes before anything else happens
+  if (ago == 0 && x_registered) { ani_host_unregister(x_registered); x_registered = nullptr; }
 
   if (use_devlist) {
     if (ago == 0) {
@@ -260,7 +284,10 @@ void PairANI::compute(int eflag, int vflag) {
 
   if (use_rccl && ago == 0) build_rccl_maps(nlocal, atom->nghost);
 
-  out_force.resize((size_t)ntotal * 3);
+  grow_out_force((size_t)ntotal * 3);
+  if (ago == 0 && pin_host && ntotal > 0 && atom->nmax >= ntotal &&
+      ani_host_register(&x[0][0], sizeof(double) * 3 * (size_t)atom->nmax) == ANI_OK)
+    x_registered = &x[0][0];
   if (eflag_atom) out_eatom.resize(use_fullnbr ? inum : nlocal);
   double out_energy = 0.0;
   double out_virial[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -271,17 +298,17 @@ void PairANI::compute(int eflag, int vflag) {
   int rc;
   if (use_devlist) {
     rc = ntotal > 0 ? ani_compute_full(ani, ntotal, nlocal, nullptr, coords, npairs, nullptr, nullptr, nullptr, /*ago=*/1,
-                                       eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, out_force.data(),
+                                       eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, out_force,
                                        eflag_atom ? out_eatom.data() : nullptr, out_virial)
                     : ANI_OK;
   } else if (use_fullnbr) {
     if (inum != nlocal) error->one(FLERR, "Pair ani: full neighbor list does not cover every local atom");
     rc = ani_compute_full(ani, ntotal, nlocal, species.data(), coords, npairs, flat_ilist.data(), flat_jlist.data(),
-                          flat_numneigh.data(), ago, eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, out_force.data(),
+                          flat_numneigh.data(), ago, eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, out_force,
                           eflag_atom ? out_eatom.data() : nullptr, out_virial);
   } else {
     rc = ani_compute_half(ani, ntotal, nlocal, species.data(), coords, npairs, atom_index12.data(), ago, eflag_atom ? 1 : 0,
-                          vflag_either ? 1 : 0, &out_energy, out_force.data(), eflag_atom ? out_eatom.data() : nullptr, out_virial);
+                          vflag_either ? 1 : 0, &out_energy, out_force, eflag_atom ? out_eatom.data() : nullptr, out_virial);
   }
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(ani));
 

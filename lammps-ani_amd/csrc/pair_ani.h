@@ -69,7 +69,16 @@ class PairANI : public Pair {
   int64_t npairs = 0;
 
   // ghost forces are reverse-communicated from here, not from atom->f (src/pair_ani.cpp:192-201)
-  std::vector<double> out_force;
+  // a plain buffer the adapter owns, page-locked (ani_host_register) so that the per-step copy of the forces is a DMA transfer
+  double* out_force = nullptr;
+  size_t out_force_cap = 0;     // doubles
+  bool out_force_pinned = false;
+  void grow_out_force(size_t doubles);
+  // the atom->x block of the current neighbour-list epoch, page-locked at ago == 0 and released at the next ago == 0 before
+  // anything else is touched (LAMMPS reallocates atom arrays only while re-neighbouring); LAMMPS_ANI_NO_PIN=1 turns both off
+  const double* x_registered = nullptr;
+  bool pin_host = true;
+  void release_pins();
   std::vector<double> out_eatom;
 
   void allocate();

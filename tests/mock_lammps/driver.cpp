@@ -1,4 +1,5 @@
 // driver.cpp — drives the PairANI adapter through the mock LAMMPS objects.  C entry points for ctypes.
+#include <chrono>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -74,6 +75,7 @@ int mock_compute(void* h, int nlocal, int nghost, const double* x, const int* ty
     for (int i = 0; i < nt; i++) { s->xrows[i] = s->x.data() + 3 * (size_t)i; s->frows[i] = s->f.data() + 3 * (size_t)i; }
     Atom* a = s->lmp.atom;
     a->x = s->xrows.data(); a->f = s->frows.data(); a->type = s->type.data(); a->nlocal = nlocal; a->nghost = nghost;
+    a->nmax = nt;
     if (ago == 0) {
       s->numneigh.assign(numneigh, numneigh + nlocal);
       size_t tot = 0;
@@ -108,6 +110,43 @@ int mock_compute(void* h, int nlocal, int nghost, const double* x, const int* ty
     *eng_vdwl = s->pair->eng_vdwl;
     for (int k = 0; k < 6; k++) virial6[k] = s->pair->virial[k];
     if ((eflag & 2) && eatom_out) for (int i = 0; i < nlocal; i++) eatom_out[i] = s->pair->eatom[i];
+    return 0;
+  } catch (const std::exception& e) {
+    s->err = e.what();
+    return 1;
+  }
+}
+
+// The adapter's own cost per timestep, as LAMMPS' Verlet loop would see it: nsteps calls of PairANI::compute on the session's
+// PERSISTENT arrays (the state mock_compute left: call it once with ago = 0 first), positions nudged in place between calls
+// (a deterministic jitter of 1e-4 A: the cached list stays valid), a re-neighbouring call (ago = 0, same list handed over again)
+// every `every` steps, eflag = vflag = 0 as on a step without thermo output.  Only the compute() calls are timed.
+// out_ms[0] = mean plain step, out_ms[1] = mean re-neighbouring step (0 if none), out_ms[2] = checksum of f (keeps the work alive)
+int mock_md_loop(void* h, int nsteps, int every, double* out_ms) {
+  Session* s = (Session*)h;
+  try {
+    Atom* a = s->lmp.atom;
+    const int nt = a->nlocal + a->nghost;
+    if (!s->pair || nt == 0 || (int)s->x.size() != 3 * nt) { s->err = "mock_md_loop: call mock_compute with ago = 0 first"; return 1; }
+    double t_plain = 0.0, t_reb = 0.0, sum = 0.0;
+    int n_plain = 0, n_reb = 0;
+    for (int k = 1; k <= nsteps; k++) {
+      const double d = 1e-4 * ((k & 1) ? 1.0 : -1.0);
+      for (int i = 0; i < a->nlocal; i++) s->x[3 * (size_t)i + (k % 3)] += d;
+      // ghosts follow their owners (the forward communication of a real run)
+      for (int g = 0; g < a->nghost; g++) s->x[3 * (size_t)(a->nlocal + g) + (k % 3)] += d;
+      for (size_t i = 0; i < s->f.size(); i++) s->f[i] = 0.0;   // force_clear
+      const bool reb = every > 0 && k % every == 0;
+      s->lmp.neighbor->ago = reb ? 0 : (every > 0 ? k % every : k);
+      const auto t0 = std::chrono::steady_clock::now();
+      s->pair->compute(0, 0);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (reb) { t_reb += ms; n_reb++; } else { t_plain += ms; n_plain++; }
+      sum += s->f[0] + s->f[s->f.size() / 2];
+    }
+    out_ms[0] = n_plain ? t_plain / n_plain : 0.0;
+    out_ms[1] = n_reb ? t_reb / n_reb : 0.0;
+    out_ms[2] = sum;
     return 0;
   } catch (const std::exception& e) {
     s->err = e.what();

@@ -70,6 +70,7 @@ class Atom {
   double **x = nullptr, **f = nullptr;
   int* type = nullptr;
   int nlocal = 0, nghost = 0, ntypes = 0;
+  int nmax = 0;   // rows allocated in x / f
 };
 
 class Force {
