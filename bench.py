@@ -212,7 +212,7 @@ def adapter_path(inp, model_path, nsteps=40, every=20):
                               0, 1, 0, f.ctypes.data, e.ctypes.data, v.ctypes.data, None)
         ms = np.zeros(3)
         if rc == 0:
-            rc = lib.mock_md_loop(h, 10, every, ms.ctypes.data)        # warm-up (registrations, first-use costs)
+            rc = lib.mock_md_loop(h, 12, 4, ms.ctypes.data)            # warm-up, re-neighbouring calls included (first-use costs)
         if rc == 0:
             rc = lib.mock_md_loop(h, nsteps, every, ms.ctypes.data)
         out[source] = {"plain_ms_per_step": float(ms[0]), "reneighbour_ms_per_step": float(ms[1]),
@@ -399,12 +399,9 @@ def main():
         ani.phase_timing(1)
         ani.phase_timing(0)
         b0, t0 = run.nbuilds, time.perf_counter()
-        for k in range(steps):
-            if k % 4 == 0:
-                ani.phase_timing(2)
-            run.step()
-            if k % 4 == 0:
-                ani.phase_timing(0)
+        # `run K` (no per-step output): the phase events of the library are recorded on every fourth step only
+        run.run(steps, before_forces=lambda k: ani.phase_timing(2) if k % 4 == 0 else None,
+                after_forces=lambda k: ani.phase_timing(0) if k % 4 == 0 else None)
         sync_all()
         dt = max_over_ranks(time.perf_counter() - t0)
         ph = ani.phase_times()
@@ -425,8 +422,7 @@ def main():
             # of a plain step and the surcharge of a re-neighbouring step (two windows, two unknowns).
             nb0, n_post, t1 = run.nbuilds, 0, time.perf_counter()
             while n_post < 600 and (run.nbuilds - nb0 < 3 or n_post < 100):
-                for _ in range(run.every):
-                    run.step()
+                run.run(run.every)
                 n_post += run.every
             sync_all()
             t_post = max_over_ranks(time.perf_counter() - t1)

@@ -115,6 +115,20 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
                             int eflag_atom, int vflag, double* d_f, double* d_ev, double* d_eatom, void* stream);
 
 /*
+ * Ghosts that are images of the rank's OWN atoms (one rank with periodic boundaries; the self-images of a rank whose brick spans
+ * the box in some direction): their two exchanges of a step folded into the step's own first and last kernel.  With a fold
+ * installed, ani_compute_full_device
+ *   - computes the position of ghost g (atom nlocal + g) as d_x[d_owner[g]] + d_shift[g] and writes it to d_x as well (the
+ *     forward communication: d_x is written although the prototype says const), and
+ *   - adds the force rows of an atom's images into the atom's own row of d_f; the ghost rows of d_f are NOT written (the reverse
+ *     communication, comm->reverse_comm(this) of src/pair_ani.cpp:197-201 for a one-rank run).
+ * Every ghost must be such an image (d_owner[g] in [0, nlocal)): a mixed ghost shell keeps its exchange kernels.  The maps belong
+ * to a list epoch: installed after the list (ago == 0 call or ani_build_list_device), cleared by the next one; device pointers,
+ * kept, not copied.  d_owner == NULL clears.  fp32 handles only.  One host synchronisation (rebuild steps only).
+ */
+int ani_set_ghost_fold(ani_handle* h, const int64_t* d_owner, const double* d_shift, int nghost, void* stream);
+
+/*
  * The same device-resident step in three calls, cut where a domain-decomposed caller exchanges ghost data, so that
  * both exchanges can run on another stream beside the work that does not need them (the reference has no
  * counterpart: its forward / reverse communication are LAMMPS' blocking MPI swaps around PairANI::compute,

@@ -29,6 +29,13 @@ int ani_md_initial_integrate(double* x, double* v, const double* f, const double
 int ani_md_final_integrate(double* v, double* f, const double* dtfm, int nlocal, int langevin, const double* g1,
                            const double* g2, const int64_t* tag, uint64_t seed, uint64_t step, void* stream);
 
+/* ani_md_final_integrate of the step that ends (its `step` number) followed by ani_md_initial_integrate of the step that begins, in
+ * one pass: for stretches of a run in which nothing looks at the full-step velocities between two steps.  Same arithmetic, same
+ * rounding as the two calls. */
+int ani_md_final_initial_integrate(double* x, double* v, double* f, const double* dtfm, double dt, int nlocal, int langevin,
+                                   const double* g1, const double* g2, const int64_t* tag, uint64_t seed, uint64_t step,
+                                   const double* x_built, double* d2max, void* stream);
+
 /* Comm::forward_comm on one rank (periodic self-images):  x[nlocal + g] = x[owner[g]] + shift[g] */
 int ani_md_forward_ghosts(double* x, const int64_t* owner, const double* shift, int nlocal, int nghost, void* stream);
 

@@ -22,7 +22,7 @@ EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
            "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times",
            "ani_trace_push", "ani_trace_pop", "ani_trace_mark", "ani_step_begin", "ani_step_ghosts_ready", "ani_step_finish",
-           "ani_debug_fused_stamps", "ani_attach_comm", "ani_debug_fused_schedule", "ani_last_mlp_kernel", "ani_host_register", "ani_host_unregister"]
+           "ani_debug_fused_stamps", "ani_attach_comm", "ani_debug_fused_schedule", "ani_last_mlp_kernel", "ani_host_register", "ani_host_unregister", "ani_set_ghost_fold"]
 # include/ani_comm.h: the device-side ghost exchange over RCCL
 COMM_EXPORTS = ["ani_comm_get_unique_id", "ani_comm_create", "ani_comm_destroy", "ani_comm_last_error", "ani_comm_rank",
                 "ani_comm_size", "ani_comm_plan", "ani_comm_exchange_counts", "ani_comm_alltoallv", "ani_comm_set_epoch",
@@ -95,6 +95,7 @@ def lib():
         L.ani_debug_colmap.argtypes = [C.c_void_p, C.c_void_p]
         L.ani_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.ani_last_mlp_kernel.argtypes = [C.c_void_p]
+        L.ani_set_ghost_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ani_host_register.argtypes = [C.c_void_p, C.c_size_t]
         L.ani_host_unregister.argtypes = [C.c_void_p]
         L.ani_last_mlp_kernel.restype = C.c_char_p
@@ -103,6 +104,9 @@ def lib():
                                                C.c_void_p, C.c_void_p]
         L.ani_md_final_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.ani_md_final_initial_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p]
         L.ani_md_forward_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ani_md_reverse_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ani_md_pack_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -264,6 +268,10 @@ class ANI:
 
     def set_option(self, name: str, value: int):
         self._check(self._lib.ani_set_option(self._h, name.encode(), int(value)))
+
+    def set_ghost_fold(self, d_owner, d_shift, nghost: int, stream=None):
+        """ani_set_ghost_fold: device addresses of owner[nghost] (int64) and shift[nghost][3] (float64); None clears"""
+        self._check(self._lib.ani_set_ghost_fold(self._h, d_owner, d_shift, int(nghost), stream))
 
     def last_mlp_kernel(self) -> str:
         return self._lib.ani_last_mlp_kernel(self._h).decode()

@@ -167,6 +167,10 @@ struct ani_handle {
   DevBuf<int> species, ilist, numneigh, jlist, jraw, nbr_off, row_of_centre, centre_of_row, bucket_info, err_flag;
   DevBuf<int> row_of_atom;   // [ntotal] AEV row of an atom, -1 for atoms that are no centres (AevArgs::row_of_atom)
   DevBuf<unsigned> sym_acc;  // [ntotal] scratch of the list symmetry check (launch_list_symmetry)
+  // ghost fold of the epoch (ani_set_ghost_fold): maps of the caller + the chains of images made from them
+  GhostFold fold;
+  int fold_nghost = -1;      // -1: none installed (every list build clears it)
+  DevBuf<int> fold_head, fold_next, fold_bad;
   bool warned_asymmetric = false;
   bool list_is_ours = false; // the installed list was built by ani_build_list*: symmetric by construction
   bool list_symmetric = true;  // this epoch's list passed the check (or is ours): the symmetric radial collection may run
@@ -425,6 +429,7 @@ int rebuild(ani_handle* h, hipStream_t st) {
   roctxMarkA("neighbor list rebuilt");   // src/ani_csrc/ani.cpp:128,215
   TraceRange tr("ani: list epoch set-up (offsets, species buckets, segment sort)");
   h->need_origin = true;
+  h->fold_nghost = -1;       // the maps belonged to the list before
   h->classes_valid = false;
   h->split_phase = 0;
   const int nlocal = h->nlocal;
@@ -1012,6 +1017,7 @@ struct StepCtx {
   const double* d_x = nullptr;
   int eflag_atom = 0, vflag = 0, f_accumulate = 0;
   double *d_f = nullptr, *d_ev = nullptr, *d_eatom = nullptr;
+  bool fold = false;   // whole-step device call: an installed ghost fold applies (pack gathers the images, finish folds their forces)
 };
 
 int step_prologue(ani_handle* h, const StepCtx& c, bool timed, hipStream_t st) {
@@ -1049,8 +1055,9 @@ int step_prologue(ani_handle* h, const StepCtx& c, bool timed, hipStream_t st) {
 
 // atoms [i0, i1) -> fp32 positions, force accumulators cleared; `first`: also the step's virial / energy accumulators
 void step_pack(ani_handle* h, const StepCtx& c, int i0, int i1, bool first, hipStream_t st) {
+  const bool fold = h->fold_nghost >= 0 && c.fold;
   launch_pack(c.d_x, h->species.p, i0, i1, h->cmap, h->xyzs.p, h->fbuf.p, first ? h->virial_acc.p : nullptr,
-              first ? c.d_ev : nullptr, h->origin.p, st);
+              first ? c.d_ev : nullptr, h->origin.p, st, fold ? &h->fold : nullptr);
 }
 
 // rows: 0 = every row, 1 = the rows with a ghost among their candidates, 2 = the others (fast path only)
@@ -1137,14 +1144,19 @@ void step_finish(ani_handle* h, const StepCtx& c, int atom0, int atom1, bool ene
   fa.f_out = c.d_f; fa.f_accumulate = c.f_accumulate; fa.ev_out = c.d_ev;
   fa.eatom_out = c.eflag_atom ? c.d_eatom : nullptr;
   fa.err_flag = h->err_flag.p;
+  if (h->fold_nghost >= 0 && c.fold) {
+    fa.fold_head = h->fold_head.p; fa.fold_next = h->fold_next.p; fa.fold_nlocal = h->nlocal;
+    fa.atom1 = std::min(fa.atom1, h->nlocal);   // the ghost rows of d_f are not written: their forces went home
+  }
   launch_finish(fa, st);
   if (energy && m.has_rep) launch_repulsion_energy(h->erep.p, kVirialSlots, c.d_ev, st);
 }
 
 int run_step(ani_handle* h, const double* d_x, int eflag_atom, int vflag, double* d_f, int f_accumulate, double* d_ev,
-             double* d_eatom, hipStream_t st) {
+             double* d_eatom, hipStream_t st, bool fold = false) {
   if (!h->use_single) return run_step64(h, d_x, eflag_atom, vflag, d_f, f_accumulate, d_ev, d_eatom, st);
   StepCtx c;
+  c.fold = fold;
   c.d_x = d_x; c.eflag_atom = eflag_atom; c.vflag = vflag; c.f_accumulate = f_accumulate; c.d_f = d_f; c.d_ev = d_ev; c.d_eatom = d_eatom;
   TraceRange tr_step("ani: step");
   int rc = step_prologue(h, c, true, st);
@@ -1310,7 +1322,7 @@ void ani_destroy(ani_handle* h) {
     if (n.b_out64) (void)hipFree(n.b_out64);
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
-  h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release(); h->row_ctr.release(); h->row_of_atom.release();
+  h->fold_head.release(); h->fold_next.release(); h->fold_bad.release(); h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release(); h->row_ctr.release(); h->row_of_atom.release();
   h->xyzs.release(); h->cl_xyz.release(); h->cl_hdr.release(); h->cl_j.release(); h->row_info.release(); h->row_flag.release(); h->row_list.release(); h->row_count.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->origin.release();
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
@@ -1361,7 +1373,7 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
     if (rc) return rc;
     h->have_list = true;
   }
-  rc = run_step(h, d_x, eflag_atom, vflag, d_f, /*accumulate=*/h->dev_overwrite ? 0 : 1, d_ev, d_eatom, st);
+  rc = run_step(h, d_x, eflag_atom, vflag, d_f, /*accumulate=*/h->dev_overwrite ? 0 : 1, d_ev, d_eatom, st, /*fold=*/true);
   // LAMMPS_ANI_PROFILING (src/pair_ani_kokkos.cpp:68-70,210-212): the host's timers see the device work of this call
   if (rc == ANI_OK && h->profiling) HIP_TRY(h, hipStreamSynchronize(st));
   return rc;
@@ -1660,6 +1672,29 @@ int ani_host_register(const void* p, size_t bytes) {
 int ani_host_unregister(const void* p) {
   if (!p) return ANI_ERR_ARG;
   if (hipHostUnregister(const_cast<void*>(p)) != hipSuccess) { (void)hipGetLastError(); return ANI_ERR_DEVICE; }
+  return ANI_OK;
+}
+
+int ani_set_ghost_fold(ani_handle* h, const int64_t* d_owner, const double* d_shift, int nghost, void* stream) {
+  if (!h) return ANI_ERR_ARG;
+  if (!d_owner || nghost < 0) { h->fold_nghost = -1; return ANI_OK; }   // cleared
+  if (!h->use_single) { h->err = "ani_set_ghost_fold: the fp64 kernels do not fold ghosts (use the exchange kernels)"; return ANI_ERR_ARG; }
+  if (!h->have_list || nghost != h->ntotal - h->nlocal) { h->err = "ani_set_ghost_fold: no list installed, or nghost differs from the list's"; return ANI_ERR_ARG; }
+  if (!d_shift && nghost > 0) { h->err = "ani_set_ghost_fold: null shift"; return ANI_ERR_ARG; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(h, h->fold_head.reserve((size_t)std::max(h->nlocal, 1)));
+  HIP_TRY(h, h->fold_next.reserve((size_t)std::max(nghost, 1)));
+  HIP_TRY(h, h->fold_bad.reserve(1));
+  static_assert(sizeof(long long) == sizeof(int64_t), "owner indices are 64-bit");
+  launch_ghost_chain(reinterpret_cast<const long long*>(d_owner), nghost, h->nlocal, h->fold_head.p, h->fold_next.p, h->fold_bad.p, st);
+  int bad = 0;
+  HIP_TRY(h, hipMemcpyAsync(&bad, h->fold_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(h, hipStreamSynchronize(st));   // once per re-neighbouring
+  HIP_TRY(h, take_launch_error());
+  if (bad) { h->fold_nghost = -1; h->err = "ani_set_ghost_fold: an owner index lies outside [0, nlocal)"; return ANI_ERR_ARG; }
+  h->fold.owner = reinterpret_cast<const long long*>(d_owner); h->fold.shift = d_shift; h->fold.nlocal = h->nlocal;
+  h->fold_nghost = nghost;
   return ANI_OK;
 }
 

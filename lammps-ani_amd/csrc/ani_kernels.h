@@ -169,8 +169,15 @@ struct SpeciesMap { int m[kMaxSpecies]; };
 // positions are stored relative to d_origin[3] (device; launch_origin sets it to the midpoint of the atoms' bounding box)
 void launch_origin(const double* d_x, int ntotal, double* d_origin, hipStream_t st);
 // atoms [i0, i1); virial_acc / ev_zero may be NULL (a second launch of a step for the ghost atoms clears neither)
+// ghosts that are images of this rank's own atoms (ani_set_ghost_fold): ghost g (atom nlocal + g) = atom owner[g] displaced by shift[g]
+struct GhostFold {
+  const long long* owner = nullptr;
+  const double* shift = nullptr;
+  int nlocal = 0;
+};
+void launch_ghost_chain(const long long* d_owner, int nghost, int nlocal, int* d_head, int* d_next, int* d_bad, hipStream_t st);
 void launch_pack(const double* d_x, const int* d_species, int i0, int i1, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
-                 double* virial_acc, double* ev_zero, const double* d_origin, hipStream_t st);
+                 double* virial_acc, double* ev_zero, const double* d_origin, hipStream_t st, const GhostFold* gf = nullptr);
 // rebuild time: list[0 .. count[0]) = the rows with a ghost atom (index >= nlocal) among their candidates, ascending; then
 // the other rows, ascending.  flag: scratch, [nrows]
 void launch_row_classes(const int4* row_info, const int* jlist, int nrows, int nlocal, int* flag, int* list, int* count, hipStream_t st);
@@ -312,6 +319,9 @@ struct FinishArgs {
   double* ev_out;        // [10]; [0] is ADDED to (zeroed by launch_pack), [1..9] written when virial_acc is given
   double* eatom_out;     // [nlocal] indexed by centre, or NULL
   const int* err_flag;   // capacity overflow flag: energy becomes NaN so device-resident callers notice
+  const int* fold_head = nullptr;   // ghost fold: chain of the images of every owned atom (launch_ghost_chain), or NULL
+  const int* fold_next = nullptr;
+  int fold_nlocal = 0;
 };
 void launch_finish(const FinishArgs& a, hipStream_t st);
 

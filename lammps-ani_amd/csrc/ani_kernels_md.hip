@@ -68,6 +68,49 @@ __global__ __launch_bounds__(256) void final_integrate_kernel(double* __restrict
   }
 }
 
+// final_integrate of step n and initial_integrate of step n + 1 in one pass over the owned atoms (nothing happens between
+// them in a run without per-step output): f += thermostat;  v += s f  (the full-step velocity, not stored);  v += s f;  x += dt v
+__global__ __launch_bounds__(256) void final_initial_integrate_kernel(double* __restrict__ x, double* __restrict__ v, double* __restrict__ f,
+                                                                      const double* __restrict__ dtfm, double dt, int n, int langevin,
+                                                                      const double* __restrict__ g1, const double* __restrict__ g2,
+                                                                      const long long* __restrict__ tag, unsigned long long seed,
+                                                                      unsigned long long step, const double* __restrict__ xb,
+                                                                      double* __restrict__ d2max) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double d2 = 0.0;
+  if (i < n) {
+    const double s = dtfm[i];
+    const unsigned long long key = mix64(seed + 0x9E3779B97F4A7C15ULL * (step + 1)) ^ (0xD1B54A32D192ED03ULL * (unsigned long long)(tag ? tag[i] : i));
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double fk = f[3 * i + k];
+      double vk = v[3 * i + k];
+      if (langevin) {
+        const unsigned long long h = mix64(key + 0x9E3779B97F4A7C15ULL * (k + 1));
+        const double r = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+        fk += g1[i] * vk + g2[i] * r;
+        f[3 * i + k] = fk;
+      }
+      vk += s * fk;            // final_integrate of the step that ends
+      vk += s * fk;            // initial_integrate of the step that begins (same rounding as the two kernels)
+      const double xk = x[3 * i + k] + dt * vk;
+      v[3 * i + k] = vk;
+      x[3 * i + k] = xk;
+      const double d = xk - xb[3 * i + k];
+      d2 += d * d;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off));
+  __shared__ double wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = d2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    d2 = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    if (d2 > *reinterpret_cast<volatile double*>(d2max))
+      atomicMax(reinterpret_cast<unsigned long long*>(d2max), (unsigned long long)__double_as_longlong(d2));
+  }
+}
+
 __global__ __launch_bounds__(256) void forward_ghosts_kernel(double* __restrict__ x, const long long* __restrict__ owner,
                                                              const double* __restrict__ shift, int nlocal, int nghost) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,6 +190,16 @@ int ani_md_final_integrate(double* v, double* f, const double* dtfm, int nlocal,
   if (nlocal <= 0) return 0;
   hipLaunchKernelGGL(final_integrate_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, f, dtfm, nlocal,
                      langevin, g1, g2, reinterpret_cast<const long long*>(tag), (unsigned long long)seed, (unsigned long long)step);
+  return (int)hipGetLastError();
+}
+
+int ani_md_final_initial_integrate(double* x, double* v, double* f, const double* dtfm, double dt, int nlocal, int langevin,
+                                   const double* g1, const double* g2, const int64_t* tag, uint64_t seed, uint64_t step,
+                                   const double* x_built, double* d2max, void* stream) {
+  if (nlocal <= 0) return 0;
+  hipLaunchKernelGGL(final_initial_integrate_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, v, f, dtfm, dt,
+                     nlocal, langevin, g1, g2, reinterpret_cast<const long long*>(tag), (unsigned long long)seed,
+                     (unsigned long long)step, x_built, d2max);
   return (int)hipGetLastError();
 }
 

@@ -46,7 +46,7 @@ void launch_origin(const double* d_x, int ntotal, double* d_origin, hipStream_t 
 
 __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict__ species, int i0, int i1, SpeciesMap cmap,
                             float4* __restrict__ out, float* __restrict__ fbuf, double* __restrict__ virial_acc,
-                            double* __restrict__ ev_zero, const double* __restrict__ origin) {
+                            double* __restrict__ ev_zero, const double* __restrict__ origin, GhostFold gf) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (virial_acc && t < 9 * kVirialSlots) virial_acc[t] = 0.0;
   if (ev_zero && t < 10) ev_zero[t] = 0.0;   // the finish kernel ADDS its block sums of the energy
@@ -56,19 +56,45 @@ __global__ void pack_kernel(const double* __restrict__ x, const int* __restrict_
   // position is the index the AEV kernels use (compact index among the species present, see ani_hip.cpp:specialize).
   const int sp = species[i];
   const int cs = (sp >= 0 && sp < kMaxSpecies) ? cmap.m[sp] : 0;
-  out[i] = make_float4((float)(x[3 * i] - origin[0]), (float)(x[3 * i + 1] - origin[1]), (float)(x[3 * i + 2] - origin[2]),
-                       __int_as_float(cs));
+  double px, py, pz;
+  if (gf.owner && i >= gf.nlocal) {
+    // ghost fold (ani_set_ghost_fold): the ghost is an image of an owned atom of this very rank -- its position is the owner's
+    // plus the image shift, which is also written back to the caller's array (the forward communication of the step)
+    const int g = i - gf.nlocal;
+    const long long o = gf.owner[g];
+    px = x[3 * o] + gf.shift[3 * g]; py = x[3 * o + 1] + gf.shift[3 * g + 1]; pz = x[3 * o + 2] + gf.shift[3 * g + 2];
+    double* xw = const_cast<double*>(x);
+    xw[3 * i] = px; xw[3 * i + 1] = py; xw[3 * i + 2] = pz;
+  } else {
+    px = x[3 * i]; py = x[3 * i + 1]; pz = x[3 * i + 2];
+  }
+  out[i] = make_float4((float)(px - origin[0]), (float)(py - origin[1]), (float)(pz - origin[2]), __int_as_float(cs));
   reinterpret_cast<float4*>(fbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 void launch_pack(const double* d_x, const int* d_species, int i0, int i1, const SpeciesMap& cmap, float4* xyzs, float* fbuf,
-                 double* virial_acc, double* ev_zero, const double* d_origin, hipStream_t st) {
+                 double* virial_acc, double* ev_zero, const double* d_origin, hipStream_t st, const GhostFold* gf) {
   int nthr = i1 - i0;
   if (virial_acc && nthr < 9 * kVirialSlots) nthr = 9 * kVirialSlots;
   if (ev_zero && nthr < 10) nthr = 10;
   if (nthr <= 0) return;
   hipLaunchKernelGGL(pack_kernel, dim3((nthr + 255) / 256), dim3(256), 0, st, d_x, d_species, i0, i1, cmap,
-                     xyzs, fbuf, virial_acc, ev_zero, d_origin);
+                     xyzs, fbuf, virial_acc, ev_zero, d_origin, gf ? *gf : GhostFold{});
+}
+
+// images of an owned atom as a chain: head[owner] -> ghost -> next[ghost] -> ... -> -1 (order = arrival of the atomics)
+__global__ __launch_bounds__(256) void ghost_chain_kernel(const long long* __restrict__ owner, int nghost, int nlocal, int* __restrict__ head,
+                                                          int* __restrict__ next, int* __restrict__ bad) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nghost) return;
+  const long long o = owner[g];
+  if (o < 0 || o >= nlocal) { *bad = 1; next[g] = -1; return; }
+  next[g] = atomicExch(head + o, g);
+}
+void launch_ghost_chain(const long long* d_owner, int nghost, int nlocal, int* d_head, int* d_next, int* d_bad, hipStream_t st) {
+  note_launch_error(hipMemsetAsync(d_head, 0xff, sizeof(int) * (size_t)(nlocal > 0 ? nlocal : 1), st));
+  note_launch_error(hipMemsetAsync(d_bad, 0, sizeof(int), st));
+  if (nghost > 0) hipLaunchKernelGGL(ghost_chain_kernel, dim3((nghost + 255) / 256), dim3(256), 0, st, d_owner, nghost, nlocal, d_head, d_next, d_bad);
 }
 
 // ---- rebuild-time preparation ------------------------------------------------------------------------
@@ -305,7 +331,12 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
   }
   const int i = 3 * a.atom0 + (b - kFinishBlocks - 1) * blockDim.x + threadIdx.x;
   if (i >= 3 * a.atom1) return;
-  const double v = (double)a.fbuf[4 * (i / 3) + (i % 3)] * 627.5094738898777;  // accumulators are one float4 per atom
+  const int at = i / 3, c = i - 3 * at;
+  float acc = a.fbuf[4 * at + c];  // accumulators are one float4 per atom
+  if (a.fold_head) {               // ghost fold: the rows of the atom's images come home here (the reverse communication)
+    for (int g = a.fold_head[at]; g >= 0; g = a.fold_next[g]) acc += a.fbuf[4 * (a.fold_nlocal + g) + c];
+  }
+  const double v = (double)acc * 627.5094738898777;
   a.f_out[i] = a.f_accumulate ? a.f_out[i] + v : v;
 }
 

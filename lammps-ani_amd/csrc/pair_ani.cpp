@@ -319,7 +319,10 @@ void PairANI::compute(int eflag, int vflag) {
     ani_trace_pop();
   }
 
-  for (int i = 0; i < ntotal; i++) {
+  // with newton off nobody reads the ghost rows of f (the reference adds them all the same and says so,
+  // src/pair_ani.cpp:203-210); with newton on LAMMPS reverse-communicates f itself and needs them
+  const int nadd = force->newton ? ntotal : nlocal;
+  for (int i = 0; i < nadd; i++) {
     f[i][0] += out_force[3 * i + 0];
     f[i][1] += out_force[3 * i + 1];
     f[i][2] += out_force[3 * i + 2];

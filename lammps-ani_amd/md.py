@@ -96,6 +96,8 @@ class VerletRun:
         if env is not None and overlap is None:
             want = env not in ("", "0")
         self._overlap = bool(want and self._fused)
+        self._want_fold = os.environ.get("ANI_MD_FOLD", "1") not in ("", "0")   # measurement knob: 0 keeps the two ghost kernels
+        self._fold = False
         if self._overlap:
             # ANI_MD_OVERLAP_ONE_STREAM: measurement knob, the same cut step with everything on the compute stream
             self._comm_stream = torch.cuda.current_stream(device) if os.environ.get("ANI_MD_OVERLAP_ONE_STREAM") else \
@@ -156,6 +158,12 @@ class VerletRun:
         hi = self.dc.sub_hi + self.cutneigh + 0.25
         self.npairs = self.ani.build_list_device(self.ntotal, n, self.species.data_ptr(), self.x.data_ptr(),
                                                  self.cutneigh, lo, hi, stream=self._stream)
+        # one rank: every ghost is an image of an owned atom -- the library's first and last kernel of a step do the two ghost
+        # exchanges themselves (ani_set_ghost_fold); the maps belong to this list
+        self._fold = False
+        if self._fused and self._want_fold and not self.dc.multi and self.ani.use_single and not self._overlap:
+            self.ani.set_ghost_fold(self.dc.send_idx.data_ptr(), self.dc.send_shift.data_ptr(), self.ntotal - n, stream=self._stream)
+            self._fold = True
         self.x_built = self.x[:n].clone()
         if self._fused:
             self._d2max.zero_()
@@ -172,7 +180,9 @@ class VerletRun:
             self.f.zero_()
         self.ani.compute_device(self.ntotal, self.nlocal, None, self.x.data_ptr(), self.npairs, None, None, None, 1,
                                 self.f.data_ptr(), self.ev.data_ptr(), vflag=self.vflag, stream=self._stream)
-        if self._fused and not self.dc.multi:
+        if self._fold:
+            pass   # the finish kernel has added the images' rows into their owners'
+        elif self._fused and not self.dc.multi:
             self._check(self._md.ani_md_reverse_ghosts(self.f.data_ptr(), self.dc.send_idx.data_ptr(), self.nlocal,
                                                        self.ntotal - self.nlocal, self._stream))
         elif self._fused and self.native is not None:
@@ -234,8 +244,7 @@ class VerletRun:
             dist.all_reduce(t, group=self.group)
         return float(t)
 
-    def step(self, force_rebuild: bool = False):
-        """force_rebuild: re-neighbour in this step whatever the displacement check would say (measurements)"""
+    def _initial_integrate(self):
         # fix nve initial_integrate: v += dtf f / m ; x += dt v  (fused: + the displacement maximum of check_distance)
         if self._fused:
             self._check(self._md.ani_md_initial_integrate(self.x.data_ptr(), self.v.data_ptr(), self.f.data_ptr(),
@@ -244,6 +253,9 @@ class VerletRun:
         else:
             self.v.addcmul_(self.f[: self.nlocal], self._dtf_over_m)
             self.x[: self.nlocal].add_(self.v, alpha=self.dt)
+
+    def _middle(self, force_rebuild: bool = False):
+        """between the two integrator halves: re-neighbouring decision, ghost positions, forces, ghost forces"""
         self.step_no += 1
         self.since_build += 1
         # Neighbor::decide + check_distance (every N steps, rebuild if any atom moved more than skin/2)
@@ -267,8 +279,9 @@ class VerletRun:
             self._build_list()
         elif self._overlap:
             self._forces_overlapped()
-            self._final_integrate()
             return
+        elif self._fold:
+            pass   # the pack kernel of the step reads the images' positions from their owners (and writes them to x)
         elif self._fused and not self.dc.multi:
             self._check(self._md.ani_md_forward_ghosts(self.x.data_ptr(), self.dc.send_idx.data_ptr(), self.dc.send_shift.data_ptr(),
                                                        self.nlocal, self.ntotal - self.nlocal, self._stream))
@@ -285,7 +298,39 @@ class VerletRun:
         else:
             self.dc.forward_positions(self.x)
         self._forces()
+
+    def step(self, force_rebuild: bool = False):
+        """force_rebuild: re-neighbour in this step whatever the displacement check would say (measurements)"""
+        self._initial_integrate()
+        self._middle(force_rebuild)
         self._final_integrate()
+
+    def run(self, nsteps: int, before_forces=None, after_forces=None):
+        """``run N`` without per-step output: nothing looks at the full-step velocities between two steps, so the
+        final_integrate of a step and the initial_integrate of the next are ONE kernel (same arithmetic and rounding as
+        step() N times; the loop is in a full-step state again when this returns).  before_forces(k) / after_forces(k):
+        optional callables around the force evaluation of step k (the bench's phase-timer switches)."""
+        if nsteps <= 0:
+            return
+        if not self._fused:
+            for _ in range(nsteps):
+                self.step()
+            return
+        self._initial_integrate()
+        for k in range(nsteps):
+            if before_forces is not None:
+                before_forces(k)
+            self._middle()
+            if after_forces is not None:
+                after_forces(k)
+            if k + 1 == nsteps:
+                self._final_integrate()
+            else:
+                lang = self._g1 is not None
+                self._check(self._md.ani_md_final_initial_integrate(
+                    self.x.data_ptr(), self.v.data_ptr(), self.f.data_ptr(), self._dtfm1.data_ptr(), self.dt, self.nlocal,
+                    1 if lang else 0, self._g1.data_ptr() if lang else None, self._g2.data_ptr() if lang else None,
+                    self.tag.data_ptr(), self._seed, self.step_no, self.x_built.data_ptr(), self._d2max.data_ptr(), self._stream))
 
     def _pack_and_send_ghosts(self):
         """forward exchange on the current stream: x[nlocal:] <- the owners' positions (+ image shifts)"""

@@ -203,3 +203,51 @@ def test_md_loop_raises_on_capacity_overflow(tmp_path, hip):
         for _ in range(3):
             run.step()
     ani.close()
+
+
+def test_ghost_fold_and_fused_integrator_follow_the_plain_loop(tmp_path, hip, monkeypatch):
+    """One rank: (a) the library's pack / finish kernels doing the two ghost exchanges themselves (ani_set_ghost_fold) against
+    the loop's own forward / reverse ghost kernels; (b) `run(N)` — final_integrate of a step and initial_integrate of the next
+    as one kernel — against N calls of `step()`.  Same arithmetic; the forces differ by the order of fp32 atomics only.  60
+    steps at 0.25 fs with hot start velocities: the loop re-neighbours on the way (the maps of a fold belong to a list epoch)."""
+    import torch
+    from lammps_ani_amd import md
+    path = str(tmp_path / "gentle.anim")
+    mf.write_model(path, mf.synthetic_model("ani2x", 1, seed=1, out_scale=0.02))
+    sysm = hx.spatial_sort(hx.water_box(1536))
+    inp = hx.decompose(sysm)
+    table = np.random.default_rng(99).normal(0.0, 0.03, size=(sysm.natoms, 3))
+    dev = torch.device("cuda:0")
+
+    def trajectory(fold, fused_run, langevin=None):
+        monkeypatch.setenv("ANI_MD_FOLD", "1" if fold else "0")
+        ani = hip.ANI(path, 0)
+        run = md.VerletRun(ani, inp, sysm.boxhi - sysm.boxlo, dev, dt=0.25, box_lo=sysm.boxlo, langevin=langevin)
+        assert run._fold == fold
+        run.v = torch.as_tensor(table[run.tag.cpu().numpy()], dtype=torch.float64, device=dev)
+        if fused_run:
+            run.run(25)
+            run.run(1)
+            run.run(34)
+        else:
+            for _ in range(60):
+                run.step()
+        x = np.zeros((sysm.natoms, 3))
+        x[run.tag.cpu().numpy()] = run.x[: run.nlocal].cpu().numpy()
+        v = np.zeros((sysm.natoms, 3))
+        v[run.tag.cpu().numpy()] = run.v.cpu().numpy()
+        out = (x, v, run.potential_energy() + run.kinetic_energy(), run.nbuilds)
+        ani.close()
+        return out
+
+    base = trajectory(False, False)
+    assert base[3] >= 2                                  # it re-neighboured
+    for fold, fused in ((True, False), (False, True), (True, True)):
+        x, v, e, nb = trajectory(fold, fused)
+        assert nb == base[3]
+        assert np.abs(x - base[0]).max() < 1e-5 and np.abs(v - base[1]).max() < 1e-5, (fold, fused)
+        assert abs(e - base[2]) < 5e-3
+    # with the thermostat: the fused kernel draws the same random numbers (keyed by seed, step, tag) as final_integrate
+    a = trajectory(False, False, langevin=(300.0, 100.0))
+    b = trajectory(True, True, langevin=(300.0, 100.0))
+    assert np.abs(a[0] - b[0]).max() < 1e-5 and np.abs(a[1] - b[1]).max() < 1e-5
