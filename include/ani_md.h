@@ -53,6 +53,26 @@ int ani_md_unpack_reverse(double* f, const int64_t* owner, int nsend, const doub
 int ani_md_gather_rows(const double* src, const int64_t* idx, int n, double* out, void* stream);
 int ani_md_scatter_rows(double* dst, const int64_t* idx, int n, const double* in, void* stream);
 
+/*
+ * Re-neighbouring of the stand-in loop, natively (the reference's runs leave this to LAMMPS: Domain::pbc, Comm::borders,
+ * Neighbor::decide).
+ *   ani_md_wrap_positions     x[i][k] -> [lo[k], lo[k] + len[k]) for the periodic dimensions (bit k of periodic_mask)
+ *   ani_md_ghost_shell_count  which owned atoms are ghosts of which (brick, image) combination: atom a belongs to combination c
+ *                             when clo[c][k] <= x[a][k] < chi[c][k] for k = 0..2.  Counts per (combination, block of 256 atoms) into
+ *                             blk_cnt[ncombo * nblk], their exclusive scan into blk_off (nblk = ceil(n / 256), at least 1), and
+ *                             out_counts[0] = all hits, out_counts[1 + c] = hits of combination c (device; the caller reads them)
+ *   ani_md_ghost_shell_fill   the hits themselves, combination-major, atoms ascending: send_idx[p] = atom, send_shift[p] = cshift[c]
+ *   ani_md_append_ghosts      one rank: x[nlocal + g] = x[owner[g]] + shift[g], species[nlocal + g] = species[owner[g]]
+ *   ani_md_check              *out = *d2max (then *d2max = 0), or +inf when ev[0] is not finite
+ */
+int ani_md_wrap_positions(double* x, int n, const double* lo3, const double* len3, int periodic_mask, void* stream);
+int ani_md_ghost_shell_count(const double* x, int n, const double* clo, const double* chi, int ncombo, int* blk_cnt, int* blk_off,
+                             int* out_counts, void* stream);
+int ani_md_ghost_shell_fill(const double* x, int n, const double* clo, const double* chi, const double* cshift, int ncombo,
+                            const int* blk_off, int64_t* send_idx, double* send_shift, void* stream);
+int ani_md_append_ghosts(double* x, int* species, int nlocal, const int64_t* owner, const double* shift, int nghost, void* stream);
+int ani_md_check(double* d2max, const double* ev, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,13 @@ def lib():
         L.ani_md_final_initial_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                                      C.c_void_p, C.c_void_p]
+        L.ani_md_wrap_positions.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ani_md_ghost_shell_count.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+        L.ani_md_ghost_shell_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]
+        L.ani_md_append_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ani_md_check.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ani_md_forward_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ani_md_reverse_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ani_md_pack_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

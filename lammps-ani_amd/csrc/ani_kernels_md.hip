@@ -159,6 +159,116 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(double* __restrict__ 
   dst[3 * idx[g] + k] = in[t];
 }
 
+
+// ---- re-neighbouring of the stand-in loop, natively (LAMMPS: Domain::pbc, Comm::borders) ---------------------------------
+__global__ __launch_bounds__(256) void wrap_kernel(double* __restrict__ x, int n, double lo0, double lo1, double lo2, double l0, double l1,
+                                                   double l2, int pmask) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * n) return;
+  const int k = t % 3;
+  if (!((pmask >> k) & 1)) return;
+  const double lo = k == 0 ? lo0 : (k == 1 ? lo1 : lo2), L = k == 0 ? l0 : (k == 1 ? l1 : l2);
+  double v = x[t];
+  v -= floor((v - lo) / L) * L;
+  if (v >= lo + L) v = lo;   // a coordinate that rounds up onto the upper face
+  x[t] = v;
+}
+
+// Ghost shell: atom a is a ghost of combination c (a brick of the decomposition and an image shift) when its UNSHIFTED position
+// lies in [clo[c], chi[c]) in every dimension.  Hits are listed combination-major, atoms ascending (the order the exchange and
+// the receiver's ghost block agree on): count per (combination, block of 256 atoms), scan, fill.
+__device__ __forceinline__ bool shell_hit(const double* __restrict__ x, int a, int n, const double* __restrict__ clo,
+                                          const double* __restrict__ chi, int c) {
+  if (a >= n) return false;
+  bool in = true;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double v = x[3 * a + k];
+    in = in && v >= clo[3 * c + k] && v < chi[3 * c + k];
+  }
+  return in;
+}
+__global__ __launch_bounds__(256) void shell_count_kernel(const double* __restrict__ x, int n, const double* __restrict__ clo,
+                                                          const double* __restrict__ chi, int nblk, int* __restrict__ blk_cnt) {
+  const int b = blockIdx.x, c = blockIdx.y;
+  const bool hit = shell_hit(x, b * 256 + threadIdx.x, n, clo, chi, c);
+  __shared__ int wc[4];
+  const int cnt = __popcll(__ballot(hit));
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[c * nblk + b] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+// exclusive scan of blk_cnt[ncombo * nblk] by one block; out_counts[0] = total, out_counts[1 + c] = hits of combination c
+__global__ __launch_bounds__(1024) void shell_scan_kernel(const int* __restrict__ blk_cnt, int* __restrict__ blk_off, int ncombo, int nblk,
+                                                          int* __restrict__ out_counts) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int total_n = ncombo * nblk;
+  for (int base = 0; base < total_n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < total_n ? blk_cnt[i] : 0;
+    // inclusive scan inside the wave, then over the waves
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if ((threadIdx.x & 63) >= off) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int before = carry_s, tot = 0;
+    for (int w = 0; w < 16; w++) { if (w < (int)(threadIdx.x >> 6)) before += wsum[w]; tot += wsum[w]; }
+    if (i < total_n) blk_off[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_counts[0] = carry_s;
+  __syncthreads();
+  for (int c = threadIdx.x; c < ncombo; c += 1024) {
+    const int beg = blk_off[c * nblk];
+    const int end = c + 1 < ncombo ? blk_off[(c + 1) * nblk] : carry_s;
+    out_counts[1 + c] = end - beg;
+  }
+}
+__global__ __launch_bounds__(256) void shell_fill_kernel(const double* __restrict__ x, int n, const double* __restrict__ clo,
+                                                         const double* __restrict__ chi, const double* __restrict__ cshift, int nblk,
+                                                         const int* __restrict__ blk_off, long long* __restrict__ send_idx,
+                                                         double* __restrict__ send_shift) {
+  const int b = blockIdx.x, c = blockIdx.y, a = b * 256 + threadIdx.x;
+  const bool hit = shell_hit(x, a, n, clo, chi, c);
+  __shared__ int wc[4];
+  const unsigned long long m = __ballot(hit);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wc[wave] = __popcll(m);
+  __syncthreads();
+  if (!hit) return;
+  int pos = blk_off[c * nblk + b] + __popcll(m & ((1ULL << lane) - 1ULL));
+  for (int w = 0; w < wave; w++) pos += wc[w];
+  send_idx[pos] = a;
+  send_shift[3 * pos] = cshift[3 * c]; send_shift[3 * pos + 1] = cshift[3 * c + 1]; send_shift[3 * pos + 2] = cshift[3 * c + 2];
+}
+// one rank: the ghosts are images of owned atoms -- positions and species appended behind the owned block
+__global__ __launch_bounds__(256) void append_ghosts_kernel(double* __restrict__ x, int* __restrict__ species, int nlocal,
+                                                            const long long* __restrict__ owner, const double* __restrict__ shift, int nghost) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nghost) return;
+  const long long o = owner[g];
+#pragma unroll
+  for (int k = 0; k < 3; k++) x[3 * (size_t)(nlocal + g) + k] = x[3 * o + k] + shift[3 * g + k];
+  species[nlocal + g] = species[o];
+}
+// Neighbor::decide's look at the loop: *out = the running displacement maximum (then zeroed), or +inf when the last energy is not
+// finite (a capacity overflow or a blown-up step: the device entry points cannot return an error)
+__global__ void check_kernel(double* __restrict__ d2max, const double* __restrict__ ev, double* __restrict__ out) {
+  const double e = ev[0];
+  const bool finite = e == e && e - e == 0.0;
+  out[0] = finite ? d2max[0] : __longlong_as_double(0x7ff0000000000000LL);
+  d2max[0] = 0.0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -232,3 +342,40 @@ int ani_md_unpack_reverse(double* f, const int64_t* owner, int nsend, const doub
 }
 
 }  // extern "C"
+
+int ani_md_wrap_positions(double* x, int n, const double* lo3, const double* len3, int periodic_mask, void* stream) {
+  if (n <= 0 || !periodic_mask) return 0;
+  hipLaunchKernelGGL(wrap_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, n, lo3[0], lo3[1], lo3[2], len3[0], len3[1],
+                     len3[2], periodic_mask);
+  return (int)hipGetLastError();
+}
+
+int ani_md_ghost_shell_count(const double* x, int n, const double* clo, const double* chi, int ncombo, int* blk_cnt, int* blk_off,
+                             int* out_counts, void* stream) {
+  if (ncombo <= 0) return 0;
+  const int nblk = n > 0 ? (n + 255) / 256 : 1;
+  hipLaunchKernelGGL(shell_count_kernel, dim3(nblk, ncombo), dim3(256), 0, (hipStream_t)stream, x, n, clo, chi, nblk, blk_cnt);
+  hipLaunchKernelGGL(shell_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, blk_cnt, blk_off, ncombo, nblk, out_counts);
+  return (int)hipGetLastError();
+}
+
+int ani_md_ghost_shell_fill(const double* x, int n, const double* clo, const double* chi, const double* cshift, int ncombo,
+                            const int* blk_off, int64_t* send_idx, double* send_shift, void* stream) {
+  if (ncombo <= 0) return 0;
+  const int nblk = n > 0 ? (n + 255) / 256 : 1;
+  hipLaunchKernelGGL(shell_fill_kernel, dim3(nblk, ncombo), dim3(256), 0, (hipStream_t)stream, x, n, clo, chi, cshift, nblk, blk_off,
+                     reinterpret_cast<long long*>(send_idx), send_shift);
+  return (int)hipGetLastError();
+}
+
+int ani_md_append_ghosts(double* x, int* species, int nlocal, const int64_t* owner, const double* shift, int nghost, void* stream) {
+  if (nghost <= 0) return 0;
+  hipLaunchKernelGGL(append_ghosts_kernel, dim3((nghost + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, species, nlocal,
+                     reinterpret_cast<const long long*>(owner), shift, nghost);
+  return (int)hipGetLastError();
+}
+
+int ani_md_check(double* d2max, const double* ev, double* out, void* stream) {
+  hipLaunchKernelGGL(check_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d2max, ev, out);
+  return (int)hipGetLastError();
+}

@@ -98,6 +98,11 @@ class VerletRun:
         self._overlap = bool(want and self._fused)
         self._want_fold = os.environ.get("ANI_MD_FOLD", "1") not in ("", "0")   # measurement knob: 0 keeps the two ghost kernels
         self._fold = False
+        # one rank on the GPU: re-neighbouring (position wrap, ghost shell, buffers, displacement check) through the kernels of
+        # include/ani_md.h instead of tensor operations; ANI_MD_NATIVE_REBUILD=0 keeps the tensor forms (measurements, tests)
+        self._native_rebuild = bool(self._fused and not self.dc.multi and
+                                    os.environ.get("ANI_MD_NATIVE_REBUILD", "1") not in ("", "0"))
+        self._cap = 0
         if self._overlap:
             # ANI_MD_OVERLAP_ONE_STREAM: measurement knob, the same cut step with everything on the compute stream
             self._comm_stream = torch.cuda.current_stream(device) if os.environ.get("ANI_MD_OVERLAP_ONE_STREAM") else \
@@ -143,8 +148,84 @@ class VerletRun:
             self._lang = (self._g1[:, None].expand(-1, 3).contiguous(), self._g2[:, None].expand(-1, 3).contiguous(),
                           torch.empty((n, 3), dtype=torch.float64, device=self.device))
 
+    def _grow(self, ntotal: int):
+        """capacity buffers of the per-atom arrays that include ghosts (grown 1.5x, owned rows kept)"""
+        if ntotal <= self._cap:
+            return
+        cap = ntotal + ntotal // 2 + 64
+        n = self.nlocal
+        xb = torch.empty((cap, 3), dtype=torch.float64, device=self.device)
+        sb = torch.empty(cap, dtype=torch.int32, device=self.device)
+        xb[:n].copy_(self.x[:n])
+        sb[:n].copy_(self.species[:n])
+        self._xbuf, self._spbuf = xb, sb
+        self._fbuf = torch.zeros((cap, 3), dtype=torch.float64, device=self.device)
+        self._sidx = torch.empty(cap, dtype=torch.int64, device=self.device)
+        self._sshift = torch.empty((cap, 3), dtype=torch.float64, device=self.device)
+        self._cap = cap
+
+    def _build_list_native(self):
+        """Domain::pbc + Comm::borders + Neighbor::build of a one-rank run without tensor operations: wrap kernel, ghost shell by
+        count / scan / fill (one host read of the ghost count), ghosts appended in place, device list, ghost fold."""
+        n, dc, md, st = self.nlocal, self.dc, self._md, self._stream
+        if self._cap == 0:
+            self._grow(max(self.x.shape[0], n))
+            self._xbuilt_buf = torch.empty((n, 3), dtype=torch.float64, device=self.device)
+            self._chk_dev = torch.zeros(1, dtype=torch.float64, device=self.device)
+            self._chk_host = torch.zeros(1, dtype=torch.float64).pin_memory()
+            self._clo2 = dc._clo.reshape(-1, 3).contiguous()
+            self._chi2 = dc._chi.reshape(-1, 3).contiguous()
+            self._cshift2 = dc._shift.reshape(-1, 3).contiguous()
+            self._ncombo = int(self._clo2.shape[0])
+            nblk = max((n + 255) // 256, 1)
+            self._blk = torch.empty(2 * max(self._ncombo, 1) * nblk, dtype=torch.int32, device=self.device)
+            self._cnt_dev = torch.zeros(self._ncombo + 1, dtype=torch.int32, device=self.device)
+            self._cnt_host = torch.zeros(self._ncombo + 1, dtype=torch.int32).pin_memory()
+            self._lo3 = np.ascontiguousarray(self._box_lo_np, dtype=np.float64)
+            self._len3 = np.ascontiguousarray(self._box_len_np, dtype=np.float64)
+            self._pmask = sum(1 << k for k in range(3) if dc.periodic[k])
+        x = self._xbuf
+        self._check(md.ani_md_wrap_positions(x.data_ptr(), n, self._lo3.ctypes.data, self._len3.ctypes.data, self._pmask, st))
+        ng = 0
+        nblk = max((n + 255) // 256, 1)
+        half = max(self._ncombo, 1) * nblk
+        if self._ncombo:
+            self._check(md.ani_md_ghost_shell_count(x.data_ptr(), n, self._clo2.data_ptr(), self._chi2.data_ptr(), self._ncombo,
+                                                    self._blk.data_ptr(), self._blk[half:].data_ptr(), self._cnt_dev.data_ptr(), st))
+            self._cnt_host.copy_(self._cnt_dev, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()      # the ghost count sizes the buffers (rebuild steps only)
+            ng = int(self._cnt_host[0])
+        if n + ng > self._cap:
+            self.x, self.species = self._xbuf[:n], self._spbuf[:n]
+            self._grow(n + ng)
+            x = self._xbuf
+        if ng:
+            self._check(md.ani_md_ghost_shell_fill(x.data_ptr(), n, self._clo2.data_ptr(), self._chi2.data_ptr(), self._cshift2.data_ptr(),
+                                                   self._ncombo, self._blk[half:].data_ptr(), self._sidx.data_ptr(),
+                                                   self._sshift.data_ptr(), st))
+            self._check(md.ani_md_append_ghosts(x.data_ptr(), self._spbuf.data_ptr(), n, self._sidx.data_ptr(), self._sshift.data_ptr(), ng, st))
+        dc.send_idx, dc.send_shift = self._sidx[:ng], self._sshift[:ng]
+        dc.send_splits, dc.recv_splits, dc.nlocal, dc.nghost = [ng], [ng], n, ng
+        self.ntotal = n + ng
+        self.x, self.species, self.f = self._xbuf[: self.ntotal], self._spbuf[: self.ntotal], self._fbuf[: self.ntotal]
+        self._per_atom_factors()
+        lo = dc.sub_lo - self.cutneigh - 0.25
+        hi = dc.sub_hi + self.cutneigh + 0.25
+        self.npairs = self.ani.build_list_device(self.ntotal, n, self.species.data_ptr(), self.x.data_ptr(), self.cutneigh, lo, hi, stream=st)
+        self._fold = False
+        if self._want_fold and self.ani.use_single and not self._overlap:
+            self.ani.set_ghost_fold(dc.send_idx.data_ptr(), dc.send_shift.data_ptr(), ng, stream=st)
+            self._fold = True
+        self._xbuilt_buf.copy_(self.x[:n])
+        self.x_built = self._xbuilt_buf
+        self._check(md.ani_md_check(self._d2max.data_ptr(), self.ev.data_ptr(), self._chk_dev.data_ptr(), st))   # zeroes the maximum
+        self.since_build = 0
+        self.nbuilds += 1
+
     def _build_list(self):
         """Domain::pbc + Comm::exchange + Comm::borders + Neighbor::build."""
+        if self._native_rebuild:
+            return self._build_list_native()
         n = self.nlocal
         xo, v, tag, sp = self.dc.exchange(self.x[:n], self.v, self.tag, self.species[:n])
         self.nlocal = n = xo.shape[0]
@@ -261,20 +342,32 @@ class VerletRun:
         # Neighbor::decide + check_distance (every N steps, rebuild if any atom moved more than skin/2)
         rebuild = bool(force_rebuild)
         if not rebuild and self.since_build % self.every == 0:
-            if self._fused:
+            if self._native_rebuild:
+                # one kernel and one pinned read: the running maximum (or +inf when the last energy is not finite), then zeroed
+                self._check(self._md.ani_md_check(self._d2max.data_ptr(), self.ev.data_ptr(), self._chk_dev.data_ptr(), self._stream))
+                self._chk_host.copy_(self._chk_dev, non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+                worst = float(self._chk_host[0])
+                if worst == float("inf"):
+                    raise RuntimeError("non-finite energy from the device step: a neighbour count exceeded the kernels' LDS "
+                                       "capacity (ANI_ERR_CAPACITY) or the forces diverged")
+                rebuild = worst > (0.5 * self.skin) ** 2
+                d2 = None
+            elif self._fused:
                 d2 = self._d2max.clone()    # running maximum since the last look (monotone between rebuilds: same decision)
                 self._d2max.zero_()
             else:
                 d2 = (self.x[: self.nlocal] - self.x_built).square().sum(1).max().reshape(1) if self.nlocal else \
                     torch.zeros(1, dtype=torch.float64, device=self.device)
-            # the same host round trip carries the health of the last force evaluation: the device entry point cannot
-            # return ANI_ERR_CAPACITY (nothing synchronises), it turns the energy into NaN instead
-            d2 = torch.where(torch.isfinite(self.ev[:1]), d2, torch.full_like(d2, float("inf")))
-            worst = self._allreduce_max(d2.clone())
-            if worst == float("inf"):
-                raise RuntimeError("non-finite energy from the device step: a neighbour count exceeded the kernels' LDS "
-                                   "capacity (ANI_ERR_CAPACITY) or the forces diverged")
-            rebuild = worst > (0.5 * self.skin) ** 2
+            if d2 is not None:
+                # the same host round trip carries the health of the last force evaluation: the device entry point cannot
+                # return ANI_ERR_CAPACITY (nothing synchronises), it turns the energy into NaN instead
+                d2 = torch.where(torch.isfinite(self.ev[:1]), d2, torch.full_like(d2, float("inf")))
+                worst = self._allreduce_max(d2.clone())
+                if worst == float("inf"):
+                    raise RuntimeError("non-finite energy from the device step: a neighbour count exceeded the kernels' LDS "
+                                       "capacity (ANI_ERR_CAPACITY) or the forces diverged")
+                rebuild = worst > (0.5 * self.skin) ** 2
         if rebuild:
             self._build_list()
         elif self._overlap:
@@ -400,6 +493,12 @@ class VerletRun:
         """Run once, without touching the trajectory, the pieces of the loop that only some steps execute — the displacement
         check with its host round trip — so that their first-use costs (module loads of the tensor kernels, lazily made
         buffers) fall before a caller's timed region whatever its number of warm-up steps."""
+        if self._native_rebuild:
+            scratch = torch.zeros(1, dtype=torch.float64, device=self.device)   # not the loop's own maximum: the kernel zeroes it
+            self._check(self._md.ani_md_check(scratch.data_ptr(), self.ev.data_ptr(), self._chk_dev.data_ptr(), self._stream))
+            self._chk_host.copy_(self._chk_dev, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            return
         if self._fused:
             d2 = self._d2max.clone()
         else:

@@ -251,3 +251,45 @@ def test_ghost_fold_and_fused_integrator_follow_the_plain_loop(tmp_path, hip, mo
     a = trajectory(False, False, langevin=(300.0, 100.0))
     b = trajectory(True, True, langevin=(300.0, 100.0))
     assert np.abs(a[0] - b[0]).max() < 1e-5 and np.abs(a[1] - b[1]).max() < 1e-5
+
+
+def test_native_reneighbouring_equals_the_tensor_form(tmp_path, hip, monkeypatch):
+    """One rank: position wrap, ghost shell (count / scan / fill), appended ghosts and the displacement check through the kernels
+    of include/ani_md.h against the tensor operations of comm.DomainComm — the same ghost shell in the same order (combination-
+    major, atoms ascending), hence the same device list and, to the fp32 atomics, the same trajectory.  A small box (three
+    images per dimension are in reach of some atoms) and the benchmark-like one."""
+    import torch
+    from lammps_ani_amd import md
+    path = str(tmp_path / "gentle.anim")
+    mf.write_model(path, mf.synthetic_model("ani2x", 1, seed=1, out_scale=0.02))
+    dev = torch.device("cuda:0")
+    for natoms, steps in ((192, 30), (3000, 50)):
+        sysm = hx.spatial_sort(hx.water_box(natoms))
+        inp = hx.decompose(sysm)
+        table = np.random.default_rng(7).normal(0.0, 0.04, size=(sysm.natoms, 3))
+        res = {}
+        for native in (False, True):
+            monkeypatch.setenv("ANI_MD_NATIVE_REBUILD", "1" if native else "0")
+            ani = hip.ANI(path, 0)
+            run = md.VerletRun(ani, inp, sysm.boxhi - sysm.boxlo, dev, dt=0.25, box_lo=sysm.boxlo)
+            assert run._native_rebuild == native
+            run.v = torch.as_tensor(table[run.tag.cpu().numpy()], dtype=torch.float64, device=dev)
+            shells = [(run.ntotal, run.npairs, run.dc.send_idx.cpu().numpy().copy(), run.dc.send_shift.cpu().numpy().copy())]
+            for k in range(steps):
+                nb = run.nbuilds
+                run.step(force_rebuild=(k == 3))
+                if run.nbuilds != nb:
+                    shells.append((run.ntotal, run.npairs, run.dc.send_idx.cpu().numpy().copy(), run.dc.send_shift.cpu().numpy().copy()))
+            x = np.zeros((sysm.natoms, 3))
+            x[run.tag.cpu().numpy()] = run.x[: run.nlocal].cpu().numpy()
+            res[native] = (shells, x, run.potential_energy() + run.kinetic_energy())
+            ani.close()
+        a, b = res[False], res[True]
+        assert len(a[0]) == len(b[0]) >= 2
+        # the first shells (same start positions) are identical entry by entry; later ones only as long as no atom sits within the
+        # trajectories' fp32 noise of a shell boundary, so their sizes are compared
+        assert a[0][0][0] == b[0][0][0] and a[0][0][1] == b[0][0][1]
+        assert np.array_equal(a[0][0][2], b[0][0][2]) and np.array_equal(a[0][0][3], b[0][0][3])
+        for sa, sb in zip(a[0][1:], b[0][1:]):
+            assert abs(sa[0] - sb[0]) <= 2 and abs(sa[1] - sb[1]) <= 40
+        assert np.abs(a[1] - b[1]).max() < 1e-5 and abs(a[2] - b[2]) < 5e-3
