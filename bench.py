@@ -171,7 +171,9 @@ def adapter_path(inp, model_path, nsteps=40, every=20):
     """The path LAMMPS itself calls, timed: tests/mock_lammps (a stand-in for LAMMPS' Atom / Neighbor / Comm objects) ->
     PairANI::compute (lammps-ani_amd/csrc/pair_ani.cpp) -> ani_compute_full with HOST pointers -> forces back in atom->f.
     Persistent arrays, eflag = vflag = 0, a re-neighbouring call every `every` steps; only compute() is timed
-    (tests/mock_lammps/driver.cpp mock_md_loop).  Two list sources: the flattened LAMMPS list and the device-built list."""
+    (tests/mock_lammps/driver.cpp mock_md_loop).  Two list sources: the flattened LAMMPS list and the device-built list; the
+    third variant also sums the ghost forces on the device (keyword rcclcomm: a one-rank communicator, device copies) instead of
+    through the host's reverse communication."""
     import ctypes as C
     import numpy as np
     mock_dir = os.path.join(ROOT, "tests", "mock_lammps")
@@ -200,9 +202,9 @@ def adapter_path(inp, model_path, nsteps=40, every=20):
     out = {"what": "PairANI::compute through the mock LAMMPS objects, host-pointer entry points (what `pair_style ani` costs per step "
                    "before LAMMPS' own integrate / comm / neighbour work); eflag = vflag = 0",
            "steps": nsteps, "reneighbour_every": every}
-    for source in ("hostlist", "devlist"):
+    for source in ("hostlist", "devlist", "devlist rcclcomm"):
         h = lib.mock_create(b"real", 0)
-        args = ["5.1", model_path, "hip", "-1", "cuaev", "full", "single", source]
+        args = ["5.1", model_path, "hip", "-1", "cuaev", "full", "single"] + source.split()
         arr = (C.c_char_p * len(args))(*[a.encode() for a in args])
         if lib.mock_pair_style(h, len(args), arr, 7) != 0:
             out[source] = {"error": lib.mock_error(h).decode()}

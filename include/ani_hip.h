@@ -246,6 +246,10 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *     launch, each wave on the centre it is about to featurise, instead of as a kernel of its own in front of it; 0 = two
  *     kernels.  Same results; candidate lists longer than 256 entries and AEV shapes off the fast path take the two kernels
  *     whatever the option says.
+ *   "reuse_build_list_upload" (default 0; the LAMMPS adapter turns it on): the ani_compute_full call that follows an
+ *     ani_build_list with the SAME coordinates pointer uses the positions that call uploaded instead of uploading them again.
+ *     For callers whose array has not changed in between (the same timestep); a caller that might hand over another array at a
+ *     recycled address leaves it off.
  *   "aev_symmetric_radial" (default 1): in the backward pass a centre takes both radial terms of a pair with a neighbour that is
  *     a centre of the same call on itself (the neighbour's term read from the neighbour's dE/dAEV row) and scatters no radial
  *     gradient to it -- two thirds of the pass's global atomics; ghost neighbours keep the scatter.  0 = scatter every radial

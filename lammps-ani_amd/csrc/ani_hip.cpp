@@ -192,6 +192,8 @@ struct ani_handle {
   bool arena_valid = false;                     // ... laid out for this epoch's row counts (ensure_arena)
   // host staging for the host-pointer entry points
   std::vector<int> h_species32;
+  int reuse_upload = 0;               // ani_set_option("reuse_build_list_upload")
+  const double* x64_from = nullptr;   // ani_build_list has just uploaded these coordinates into x64: the step that follows reuses them
   std::vector<int> h_half_num, h_half_j;
 
   // phase timing
@@ -1560,7 +1562,10 @@ int ani_build_list(ani_handle* h, int ntotal, int nlocal, const int64_t* species
   HIP_TRY(h, h->x64.reserve((size_t)ntotal * 3));
   HIP_TRY(h, hipMemcpyAsync(h->species.p, h->h_species32.data(), sizeof(int) * (size_t)ntotal, hipMemcpyHostToDevice, st));
   HIP_TRY(h, hipMemcpyAsync(h->x64.p, coordinates, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyHostToDevice, st));
-  return build_list(h, ntotal, nlocal, h->species.p, h->x64.p, cutneigh, lo, hi, out_npairs, st);
+  const int rcb = build_list(h, ntotal, nlocal, h->species.p, h->x64.p, cutneigh, lo, hi, out_npairs, st);
+  // the step that follows in the same timestep passes the same array with the same contents (include/ani_hip.h): no second upload
+  h->x64_from = (rcb == ANI_OK && h->reuse_upload) ? coordinates : nullptr;
+  return rcb;
 }
 
 int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* species, const double* coordinates, int64_t npairs,
@@ -1607,7 +1612,9 @@ int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
   HIP_TRY(h, h->f64.reserve((size_t)ntotal * 3));
   HIP_TRY(h, h->ev.reserve(10));
   HIP_TRY(h, h->eatom.reserve(std::max(nlocal, 1)));
-  HIP_TRY(h, hipMemcpyAsync(h->x64.p, coordinates, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyHostToDevice, st));
+  if (h->x64_from != coordinates)   // (a re-neighbouring step of the `devlist` mode: ani_build_list uploaded them a moment ago)
+    HIP_TRY(h, hipMemcpyAsync(h->x64.p, coordinates, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyHostToDevice, st));
+  h->x64_from = nullptr;
   rc = run_step(h, h->x64.p, eflag_atom, vflag, h->f64.p, /*accumulate=*/0, h->ev.p, h->eatom.p, st);
   if (rc) return rc;
   rc = finish_host(h, ntotal, nlocal, eflag_atom, vflag, out_energy, out_force, out_atomic_energies, out_virial);
@@ -1747,6 +1754,11 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   }
   if (strcmp(name, "mlp_chain") == 0) {
     h->mlp_chain = value;
+    return ANI_OK;
+  }
+  if (strcmp(name, "reuse_build_list_upload") == 0) {
+    h->reuse_upload = value != 0;
+    h->x64_from = nullptr;
     return ANI_OK;
   }
   if (strcmp(name, "mlp_fused") == 0) {

@@ -113,6 +113,7 @@ void PairANI::create_model() {
                             use_single ? 1 : 0, &ani);
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(nullptr));
   if (profiling) ani_set_option(ani, "profiling", 1);
+  ani_set_option(ani, "reuse_build_list_upload", 1);   // devlist: ani_build_list and the step that follows see the same atom->x
   if (use_rccl) {
     // one RCCL communicator over the ranks of `world`: rank 0 makes the id, MPI carries it (the only MPI traffic of this path
     // besides the per-rebuild map exchange)
@@ -217,8 +218,13 @@ void PairANI::compute(int eflag, int vflag) {
   const int ntotal = nlocal + atom->nghost;
   const int ago = neighbor->ago;
   const int inum = use_devlist ? nlocal : list->inum;
-  // LAMMPS may have reallocated atom->x while re-neighbouring: the old block's registration goes before anything else happens
-  if (ago == 0 && x_registered) { ani_host_unregister(x_registered); x_registered = nullptr; }
+  // LAMMPS may have reallocated atom->x while re-neighbouring (memory->grow: the block moves, or grows in place and nmax with
+  // it): a registration that no longer describes the block goes before anything else happens; one that still does is kept
+  // (registering 3.5 MB costs as much as it saves over an epoch)
+  if (ago == 0 && x_registered && (x_registered != (ntotal > 0 ? &x[0][0] : nullptr) || x_registered_nmax != atom->nmax)) {
+    ani_host_unregister(x_registered);
+    x_registered = nullptr;
+  }
 
   if (use_devlist) {
     if (ago == 0) {
@@ -285,9 +291,11 @@ void PairANI::compute(int eflag, int vflag) {
   if (use_rccl && ago == 0) build_rccl_maps(nlocal, atom->nghost);
 
   grow_out_force((size_t)ntotal * 3);
-  if (ago == 0 && pin_host && ntotal > 0 && atom->nmax >= ntotal &&
-      ani_host_register(&x[0][0], sizeof(double) * 3 * (size_t)atom->nmax) == ANI_OK)
+  if (ago == 0 && pin_host && !x_registered && ntotal > 0 && atom->nmax >= ntotal &&
+      ani_host_register(&x[0][0], sizeof(double) * 3 * (size_t)atom->nmax) == ANI_OK) {
     x_registered = &x[0][0];
+    x_registered_nmax = atom->nmax;
+  }
   if (eflag_atom) out_eatom.resize(use_fullnbr ? inum : nlocal);
   double out_energy = 0.0;
   double out_virial[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -77,6 +77,7 @@ class PairANI : public Pair {
   // the atom->x block of the current neighbour-list epoch, page-locked at ago == 0 and released at the next ago == 0 before
   // anything else is touched (LAMMPS reallocates atom arrays only while re-neighbouring); LAMMPS_ANI_NO_PIN=1 turns both off
   const double* x_registered = nullptr;
+  int x_registered_nmax = 0;
   bool pin_host = true;
   void release_pins();
   std::vector<double> out_eatom;

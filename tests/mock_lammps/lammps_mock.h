@@ -200,7 +200,8 @@ class Pair : protected Pointers {
 inline void Comm::reverse_comm(Pair* p) {
   const int ng = (int)owner.size();
   if (!ng) return;
-  std::vector<double> buf(3 * (size_t)ng);
+  static thread_local std::vector<double> buf;   // LAMMPS keeps its communication buffers too
+  if (buf.size() < 3 * (size_t)ng) buf.resize(3 * (size_t)ng);
   p->pack_reverse_comm(ng, nlocal, buf.data());
   p->unpack_reverse_comm(ng, owner.data(), buf.data());
 }
