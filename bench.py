@@ -36,7 +36,7 @@ PEAK_HBM_GBS = 8000.0          # same table (spec; ~6.3 TB/s achievable)
 # published: 100 002-atom water, ANI-2x, 1 model, fp32, Kokkos, on 1 / 2 / 4 / 8 A100 (examples/benchmark/README.md:78-81)
 PUBLISHED_NS_DAY = {1: 1.495, 2: 2.774, 4: 4.846, 8: 7.663}
 PEAK_16BIT_MFMA_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA peak, same table: the pipe the split products run on
-PMC_SUMMARY = "r03_pmc_summary.json"
+PMC_SUMMARY = "r04_pmc_summary.json"
 MD_OUT_SCALE = 0.02   # output-layer scale of the MD pass's model file (see md_pass)
 
 

@@ -262,7 +262,7 @@ bool launch_aev_backward(const AevParams& p, const AevArgs& a, int max_numneigh,
 bool aev_fast_path(const AevParams& p, int max_numneigh);
 // rebuild time: stable sort of every centre's neighbour segment by neighbour species (jin -> jout)
 void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_numneigh, const int* d_jin, int* d_jout,
-                       int nlocal, int S, int present_mask, hipStream_t st);
+                       int nlocal, int S, int present_mask, hipStream_t st, int in_stride = 0);
 
 // device-side neighbour list (ani_kernels_nbr.hip): cells of edge >= cutneigh over [lo, hi)
 struct NbrGrid {
@@ -284,6 +284,9 @@ void launch_nbr_count(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch
 // jlist (flattened in atom order) and the identity ilist
 void launch_nbr_fill(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, const int* d_nbr_off,
                      int* d_jlist, int* d_ilist, hipStream_t st);
+// one pass instead of launch_nbr_count + launch_nbr_fill: rows of `cap` entries, true counts, their scan, an overflow word
+void launch_nbr_onepass(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int cap, int* d_numneigh,
+                        int* d_nbr_off, int* d_jrows, int* d_ilist, int* d_ovf, hipStream_t st);
 
 // optional pairwise repulsion (ani_kernels_rep.hip)
 struct RepArgs {

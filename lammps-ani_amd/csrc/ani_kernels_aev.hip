@@ -138,11 +138,13 @@ __device__ __forceinline__ int triu_index(int s1, int s2, int S) {
 // =====================================================================================================
 __global__ __launch_bounds__(256) void sort_jlist_kernel(const int* __restrict__ species, const int* __restrict__ nbr_off,
                                                          const int* __restrict__ numneigh, const int* __restrict__ jin,
-                                                         int* __restrict__ jout, int nlocal, int S, int present) {
+                                                         int* __restrict__ jout, int nlocal, int S, int present, int in_stride) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ii = blockIdx.x * 4 + wave;
   if (ii >= nlocal) return;
   const int beg = nbr_off[ii], n = numneigh[ii];
+  // the unsorted entries: dense segments like the output, or rows of a fixed capacity (the one-pass list build)
+  jin += in_stride ? (long long)ii * in_stride - beg : 0LL;
   int outpos = 0;
   for (int s = 0; s < S; s++) {
     if (!((present >> s) & 1)) continue;   // a species that occurs nowhere in the system: no pass over the list for it
@@ -158,10 +160,10 @@ __global__ __launch_bounds__(256) void sort_jlist_kernel(const int* __restrict__
 }
 
 void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_numneigh, const int* d_jin, int* d_jout,
-                       int nlocal, int S, int present_mask, hipStream_t st) {
+                       int nlocal, int S, int present_mask, hipStream_t st, int in_stride) {
   if (nlocal <= 0) return;
   hipLaunchKernelGGL(sort_jlist_kernel, dim3((nlocal + 3) / 4), dim3(256), 0, st, d_species, d_nbr_off, d_numneigh, d_jin, d_jout,
-                     nlocal, S, present_mask);
+                     nlocal, S, present_mask, in_stride);
 }
 
 // =====================================================================================================

@@ -145,12 +145,16 @@ __global__ void nbr_gather_kernel(const double* __restrict__ x, const int* __res
 // dependent L2 load per candidate).
 constexpr int kSearchLanes = 16;
 
-template <bool FILL>
+// MODE 0: count (numneigh);  1: fill dense segments at nbr_off;  2: ONE pass -- count and fill rows of a fixed capacity `cap`
+// (entry k of centre i at jlist[i * cap + k]; entries beyond cap are counted, not written, and *ovf is set)
+template <int MODE>
 __global__ __launch_bounds__(256) void nbr_search_kernel(const double* __restrict__ xs, const int* __restrict__ order,
                                                           const int* __restrict__ cell_start, NbrGrid g, int nlocal,
                                                           int ntotal, double cut2, int* __restrict__ numneigh,
-                                                          const int* __restrict__ nbr_off, int* __restrict__ jlist) {
+                                                          const int* __restrict__ nbr_off, int* __restrict__ jlist, int cap,
+                                                          int* __restrict__ ovf) {
   constexpr int L = kSearchLanes;
+  constexpr bool FILL = MODE != 0;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int p = (int)(t / L), l = threadIdx.x & (L - 1);
   const int grp_shift = (threadIdx.x & 63) & ~(L - 1);   // where this group's bits sit in the wave ballot
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void nbr_search_kernel(const double* __restric
   cell_coords(g, xi, yi, zi, cx, cy, cz);
   const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < g.nc[0] - 1 ? cx + 1 : g.nc[0] - 1;
   int n = 0;
-  int* out = FILL ? jlist + nbr_off[i] : nullptr;
+  int* out = MODE == 1 ? jlist + nbr_off[i] : (MODE == 2 ? jlist + (size_t)i * cap : nullptr);
   for (int dz = -1; dz <= 1; dz++) {
     const int z = cz + dz;
     if (z < 0 || z >= g.nc[2]) continue;
@@ -180,12 +184,18 @@ __global__ __launch_bounds__(256) void nbr_search_kernel(const double* __restric
           hit = r2 <= cut2 && q != p;  // rsq <= cutneighsq, as LAMMPS' npair full/bin
         }
         const unsigned bits = (unsigned)(__ballot(hit) >> grp_shift) & ((1u << L) - 1u);
-        if (FILL && hit) out[n + __popc(bits & ((1u << l) - 1u))] = order[q];
+        if (FILL && hit) {
+          const int k = n + __popc(bits & ((1u << l) - 1u));
+          if (MODE == 1 || k < cap) out[k] = order[q];
+        }
         n += __popc(bits);
       }
     }
   }
-  if (!FILL && l == 0) numneigh[i] = n;
+  if (MODE != 1 && l == 0) {
+    numneigh[i] = n;
+    if (MODE == 2 && n > cap) *ovf = 1;
+  }
 }
 
 __global__ void iota_kernel(int* __restrict__ out, int n) {
@@ -210,24 +220,44 @@ void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrSc
   hipLaunchKernelGGL(nbr_gather_kernel, grid, block, 0, st, d_x, s.order, ntotal, s.xs);
 }
 
-void launch_nbr_count(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int* d_numneigh,
-                      int* d_nbr_off, hipStream_t st) {
-  if (nlocal > 0 && ntotal > 0)
-    hipLaunchKernelGGL(nbr_search_kernel<false>, dim3((unsigned)(((long long)ntotal * kSearchLanes + 255) / 256)), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
-                       nlocal, ntotal, cutneigh * cutneigh, d_numneigh, nullptr, nullptr);
+namespace {
+void nbr_scan_offsets(int nlocal, int ntotal, const NbrScratch& s, int* d_numneigh, int* d_nbr_off, hipStream_t st) {
   // cell_id is free once the atoms are binned: scratch for the chunk totals (nlocal / 4096 + 1 <= ntotal entries)
   const int nchunks = nlocal / kScanChunk + 1;
   if (nchunks > ntotal) { hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, d_numneigh, d_nbr_off, nlocal); return; }
   hipLaunchKernelGGL(scan_chunk_kernel, dim3(nchunks), dim3(1024), 0, st, d_numneigh, d_nbr_off, nlocal, s.cell_id);
   hipLaunchKernelGGL(scan_add_kernel, dim3((nlocal + 256) / 256), dim3(256), 0, st, d_nbr_off, nlocal, s.cell_id, nchunks);
 }
+}  // namespace
+
+void launch_nbr_count(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int* d_numneigh,
+                      int* d_nbr_off, hipStream_t st) {
+  if (nlocal > 0 && ntotal > 0)
+    hipLaunchKernelGGL(nbr_search_kernel<0>, dim3((unsigned)(((long long)ntotal * kSearchLanes + 255) / 256)), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
+                       nlocal, ntotal, cutneigh * cutneigh, d_numneigh, nullptr, nullptr, 0, nullptr);
+  nbr_scan_offsets(nlocal, ntotal, s, d_numneigh, d_nbr_off, st);
+}
 
 void launch_nbr_fill(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, const int* d_nbr_off,
                      int* d_jlist, int* d_ilist, hipStream_t st) {
   if (nlocal <= 0 || ntotal <= 0) return;
-  hipLaunchKernelGGL(nbr_search_kernel<true>, dim3((unsigned)(((long long)ntotal * kSearchLanes + 255) / 256)), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
-                     nlocal, ntotal, cutneigh * cutneigh, nullptr, d_nbr_off, d_jlist);
+  hipLaunchKernelGGL(nbr_search_kernel<1>, dim3((unsigned)(((long long)ntotal * kSearchLanes + 255) / 256)), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
+                     nlocal, ntotal, cutneigh * cutneigh, nullptr, d_nbr_off, d_jlist, 0, nullptr);
   hipLaunchKernelGGL(iota_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, st, d_ilist, nlocal);
+}
+
+// count and fill in one pass into rows of `cap` entries (d_jrows[nlocal * cap]); d_numneigh holds the TRUE counts, d_nbr_off
+// their scan (the dense offsets the sorted list is written at), *d_ovf = 1 if a centre has more than cap neighbours (the rows
+// are then incomplete: the caller fills a dense list with launch_nbr_fill from the counts it already has)
+void launch_nbr_onepass(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int cap, int* d_numneigh,
+                        int* d_nbr_off, int* d_jrows, int* d_ilist, int* d_ovf, hipStream_t st) {
+  note_launch_error(hipMemsetAsync(d_ovf, 0, sizeof(int), st));
+  if (nlocal > 0 && ntotal > 0) {
+    hipLaunchKernelGGL(nbr_search_kernel<2>, dim3((unsigned)(((long long)ntotal * kSearchLanes + 255) / 256)), dim3(256), 0, st, s.xs, s.order, s.cell_start, g,
+                       nlocal, ntotal, cutneigh * cutneigh, d_numneigh, nullptr, d_jrows, cap, d_ovf);
+    hipLaunchKernelGGL(iota_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, st, d_ilist, nlocal);
+  }
+  nbr_scan_offsets(nlocal, ntotal, s, d_numneigh, d_nbr_off, st);
 }
 
 }  // namespace ani

@@ -2,7 +2,7 @@
 300 K, fix langevin 300 300 100 + fix nve, dt 0.5 fs, neighbor 2.0 bin / neigh_modify every 10 check yes, 4 x 500 + 5000
 warm-up steps, then the production run (default 5000 steps, `run_steps` of the input) timed as one block.
 
-    python tools/long_run.py [atoms] [warmup] [steps] > profiles/r03_md_long_run.json
+    python tools/long_run.py [atoms] [warmup] [steps] > profiles/r04_md_long_run.json
 
 Prints one JSON line: ns/day of the production block as LAMMPS' "Performance:" line would give it (steps / wall time), with
 the number of re-neighbourings it contained, the thermostat's temperature at its end and the total-energy bookkeeping."""
@@ -35,12 +35,10 @@ ani = ani_hip.ANI(path, 0)
 run = md.VerletRun(ani, inp, system.boxhi - system.boxlo, dev, dt=0.5, langevin=(300.0, 100.0), box_lo=system.boxlo)
 run.create_velocities(300.0)
 run.warm_paths()
-for _ in range(warmup):
-    run.step()
+run.run(warmup)        # `run N` without per-step output: VerletRun.run fuses the integrator halves between steps
 torch.cuda.synchronize()
 b0, t0 = run.nbuilds, time.perf_counter()
-for _ in range(steps):
-    run.step()
+run.run(steps)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ke, pe = run.kinetic_energy(), run.potential_energy()

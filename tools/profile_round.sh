@@ -4,14 +4,14 @@
 #   * separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ)  -> pmc_summary.json, tagged with the digest of the kernel
 #     sources it was measured on (bench.py uses its numbers only while that digest still matches)
 # Run on the GPU box from the repo root:  tools/profile_round.sh [TAG]   -> gpurun_out/profile_TAG/
-TAG=${1:-r02}
+TAG=${1:-r04}
 set -uo pipefail
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run on a GPU box through gpurun (GRAFT_REPO_ROOT is unset)}" || exit 1
 OUT=gpurun_out/profile_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
 ARGS="--no-cpu-baseline --no-dense-pass --no-extra --steps 40 --warmup 5"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE"; do
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   tag=$(echo $c | cut -d' ' -f1)
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$tag -o p --output-format csv -- python bench.py $ARGS > /dev/null 2> $OUT/pmc_$tag.err
 done
