@@ -596,6 +596,9 @@ def main():
                              "(/opt/skills/guides/MI355X_MICROARCH.md); hbm_frac = counter traffic / time / 8 TB/s",
                         counters=pmc_note)
         mlp_roof["frac"] = mlp_exec_tf / mlp_peak if mlp_exec_tf else None
+        # counter view of the same thing: cycles the matrix pipes were busy / (4 SIMDs x cycles a CU was busy), while the launch ran
+        mb, cb = counter("ani::mlp_fused", "SQ_VALU_MFMA_BUSY_CYCLES"), counter("ani::mlp_fused", "SQ_BUSY_CU_CYCLES")
+        mlp_roof["mfma_busy_share"] = mb / (4.0 * cb) if mb and cb else None
         # `roofline` is the kernel with the largest share of the step (row 1 of the rocprofv3 --stats summary of this command)
         roofs = sorted([(t_mlp, mlp_roof), (t_bwd, bwd_roof), (t_f, fwd_roof)], key=lambda r: -r[0])
         main_roof, other_roofs = roofs[0][1], [r[1] for r in roofs[1:]]
