@@ -304,15 +304,27 @@ def main():
             self.d_ev = torch.zeros(10, dtype=torch.float64, device=dev)
             self.ex = comm.GhostExchange(inp, self.system.boxhi - self.system.boxlo, dev)
             self.stream = torch.cuda.current_stream().cuda_stream
+            # one rank: the ghost-force sum of the pair style as the loop's own kernel (include/ani_md.h), forces overwritten by
+            # the library -- no tensor operation inside the timed steps
+            self.native_reverse = world == 1
+            if self.native_reverse:
+                self.ani.set_option("device_overwrite_forces", 1)
+                self.d_owner = torch.from_numpy(inp.owner_lidx.astype(np.int64)).to(dev)
 
         def step(self, ago):
             inp = self.inp
-            self.d_f.zero_()
+            if not self.native_reverse:
+                self.d_f.zero_()
             self.ani.compute_device(inp.ntotal, inp.nlocal, self.d_species.data_ptr(), self.d_x.data_ptr(), inp.npairs,
                                     self.d_ilist.data_ptr(), self.d_jlist.data_ptr(), self.d_numneigh.data_ptr(), ago,
                                     self.d_f.data_ptr(), self.d_ev.data_ptr(), None, eflag_atom=False, vflag=bool(args.vflag),
                                     stream=self.stream)
-            self.ex.reverse_add(self.d_f.view(-1, 3))
+            if self.native_reverse:
+                rc = ani_hip.lib().ani_md_reverse_ghosts(self.d_f.data_ptr(), self.d_owner.data_ptr(), inp.nlocal, inp.nghost, self.stream)
+                if rc:
+                    raise RuntimeError(f"ani_md_reverse_ghosts: hipError {rc}")
+            else:
+                self.ex.reverse_add(self.d_f.view(-1, 3))
 
         def timed_run(self, nsteps, warmup):
             self.ani.phase_timing(1)   # the event pool is made now

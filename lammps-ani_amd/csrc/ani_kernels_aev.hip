@@ -1209,10 +1209,21 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
                                                 const RepTab& rep, float& er, PF&& before_final_scatter BWD_STAMP_PARAMS) {
   constexpr int NR = 16;
   const int centre = h[0];
+  const int nrad = hdr_nrad(h), nang = hdr_nang(h);
+  // the rows of the neighbours that are centres themselves (symmetric radial collection, below): asked for here, in front of
+  // the centre's set-up, instead of inside the radial stage -- where the lookup stood between the entry and the row it selects,
+  // two dependent round trips in a row
+  int rjp[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; k++) {
+    rjp[k] = -1;
+#ifndef ANI_RAD_NOREC
+    if (a.row_of_atom && 64 * k + lane < nrad) rjp[k] = a.row_of_atom[cl_index(pf.jj[k])];
+#endif
+  }
 #pragma unroll
   for (int c = 0; c < GR; c++)
     if (lane + 64 * c < (p.aev_stride >> 2)) reinterpret_cast<float4*>(L.row)[lane + 64 * c] = pf.grow[c];
-  const int nrad = hdr_nrad(h), nang = hdr_nang(h);
   {
     // starts of the species groups in the angular list (the pair table is built from them): lane s takes its count out of the
     // header and a three-level DPP scan makes the prefix; lane S ends up with the total
@@ -1265,7 +1276,11 @@ __device__ __forceinline__ void backward_centre(const AevParams& p, const AevArg
     float gsx = 0.f, gsy = 0.f, gsz = 0.f;   // sym: what the centre adds to its own force beyond (gx, gy, gz)
     int rj = -1;
 #ifndef ANI_RAD_NOREC
-    if (a.row_of_atom && live) rj = a.row_of_atom[j];
+    if (c < NCH) {
+#pragma unroll
+      for (int k = 0; k < NCH; k++)
+        if (c == k) rj = rjp[k];
+    } else if (a.row_of_atom && live) rj = a.row_of_atom[j];
 #endif
     const bool sym = rj >= 0;
     if (live) {
