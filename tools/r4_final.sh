@@ -9,6 +9,6 @@ timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.er
 for n in 12501 25002 50001; do timeout -k 10 300 python bench.py --no-cpu-baseline --no-dense-pass --no-extra --atoms $n > $O/bench_$n.json 2> $O/bench_$n.err; done
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_steps20_warmup5.json 2> /dev/null
 timeout -k 10 300 python tools/long_run.py > $O/md_long_run.json 2> $O/md_long_run.err
-timeout -k 10 300 python tools/md_probe.py 100002 1000 0.5 1 300 > $O/md_nve_100k_1000steps.log 2>&1
+timeout -k 10 300 python tools/md_probe.py 100002 1000 0.25 1 300 > $O/md_nve_100k_1000steps.log 2>&1
 timeout -k 10 300 python tools/members_probe.py "" > $O/members_probe.log 2>&1
 echo done
