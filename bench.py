@@ -463,6 +463,16 @@ def main():
             info["rebuild_surcharge_ms"] = info["rebuild_ms"] - info["plain_ms_per_step"]
             info["rebuild_note"] = ("single synchronised steps, median of 5: a plain step and a step forced to re-neighbour; "
                                     "amortised_ms_per_step is the rate of the long window, re-neighbourings included")
+            # a sustained block, untimed for `value` but reported: long enough (about two seconds of back-to-back steps) that a
+            # coarse outside sampler of GPU activity sees the run, and a second, independent reading of the loop's rate
+            n_sus = int(min(max(2.0 / max(dt / steps, 1e-5), 500), 20000)) // run.every * run.every
+            sync_all()
+            nb1, t2 = run.nbuilds, time.perf_counter()
+            run.run(n_sus)
+            sync_all()
+            t_sus = max_over_ranks(time.perf_counter() - t2)
+            info["sustained_window"] = {"steps": n_sus, "list_rebuilds": run.nbuilds - nb1, "ms_per_step": t_sus / n_sus * 1e3,
+                                        "ns_per_day": n_sus / t_sus * 0.0432, "wall_s": t_sus}
             info["energy_finite"] = info["energy_finite"] and bool(np.isfinite(run.potential_energy()))
         view = ani.debug_view()
         ani.close()
