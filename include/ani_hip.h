@@ -127,6 +127,13 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
  * kept, not copied.  d_owner == NULL clears.  fp32 handles only.  One host synchronisation (rebuild steps only).
  */
 int ani_set_ghost_fold(ani_handle* h, const int64_t* d_owner, const double* d_shift, int nghost, void* stream);
+/*
+ * The same fold handed over BEFORE the list it belongs to: the next ani_build_list_device / ani_build_list installs it with the
+ * list it builds (nghost must equal that list's ntotal - nlocal, otherwise it is dropped), and its check -- every owner inside
+ * [0, nlocal) -- comes back behind the synchronisation the build has anyway instead of one of its own; a failed check makes the
+ * build return ANI_ERR_ARG.  Nothing is enqueued by this call.  d_owner == NULL clears what was staged.
+ */
+int ani_stage_ghost_fold(ani_handle* h, const int64_t* d_owner, const double* d_shift, int nghost);
 
 /*
  * The same device-resident step in three calls, cut where a domain-decomposed caller exchanges ghost data, so that
@@ -246,6 +253,11 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *     launch, each wave on the centre it is about to featurise, instead of as a kernel of its own in front of it; 0 = two
  *     kernels.  Same results; candidate lists longer than 256 entries and AEV shapes off the fast path take the two kernels
  *     whatever the option says.
+ *   "nbr_sorted_rows" (default 1): ani_build_list* searches the cells and groups every centre's neighbours by species in ONE kernel,
+ *     into rows of a capacity taken from the longest list of the build before (a build that overflows its rows, and the first one
+ *     of a handle, counts and fills dense segments instead); ani_debug_list then returns row offsets i * capacity.  0 = separate
+ *     search and grouping kernels.  "nbr_onepass" 0 = always count first, then fill.  "nbr_half_cells" (default 0): cells of half
+ *     the cutoff, 5 x 5 x 5 of them searched.  The same neighbour sets in every case.
  *   "reuse_build_list_upload" (default 0; the LAMMPS adapter turns it on): the ani_compute_full call that follows an
  *     ani_build_list with the SAME coordinates pointer uses the positions that call uploaded instead of uploading them again.
  *     For callers whose array has not changed in between (the same timestep); a caller that might hand over another array at a

@@ -22,7 +22,7 @@ EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
            "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times",
            "ani_trace_push", "ani_trace_pop", "ani_trace_mark", "ani_step_begin", "ani_step_ghosts_ready", "ani_step_finish",
-           "ani_debug_fused_stamps", "ani_attach_comm", "ani_debug_fused_schedule", "ani_last_mlp_kernel", "ani_host_register", "ani_host_unregister", "ani_set_ghost_fold"]
+           "ani_debug_fused_stamps", "ani_attach_comm", "ani_debug_fused_schedule", "ani_last_mlp_kernel", "ani_host_register", "ani_host_unregister", "ani_set_ghost_fold", "ani_stage_ghost_fold"]
 # include/ani_comm.h: the device-side ghost exchange over RCCL
 COMM_EXPORTS = ["ani_comm_get_unique_id", "ani_comm_create", "ani_comm_destroy", "ani_comm_last_error", "ani_comm_rank",
                 "ani_comm_size", "ani_comm_plan", "ani_comm_exchange_counts", "ani_comm_alltoallv", "ani_comm_set_epoch",
@@ -96,6 +96,7 @@ def lib():
         L.ani_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.ani_last_mlp_kernel.argtypes = [C.c_void_p]
         L.ani_set_ghost_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ani_stage_ghost_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.ani_host_register.argtypes = [C.c_void_p, C.c_size_t]
         L.ani_host_unregister.argtypes = [C.c_void_p]
         L.ani_last_mlp_kernel.restype = C.c_char_p
@@ -254,8 +255,15 @@ class ANI:
         pn, po, pj = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self._check(self._lib.ani_debug_list(self._h, C.byref(pn), C.byref(po), C.byref(pj)))
         nn = self.debug_read(pn, (nlocal,), np.int32)
-        jl = self.debug_read(pj, (int(nn.sum()),), np.int32)
-        return nn, jl
+        if nlocal == 0:
+            return nn, np.zeros(0, np.int32)
+        # dense segments, or rows of a fixed capacity (the one-kernel build): gathered into dense segments here
+        off = self.debug_read(po, (nlocal + 1,), np.int32)
+        span = self.debug_read(pj, (int((off[:-1] + nn).max()),), np.int32)
+        if np.array_equal(off[1:] - off[:-1], nn):
+            return nn, span[: int(nn.sum())]
+        idx = np.repeat(off[:-1] - np.concatenate([[0], np.cumsum(nn)[:-1]]), nn) + np.arange(int(nn.sum()))
+        return nn, span[idx]
 
     def debug_view(self) -> DebugView:
         v = DebugView()
@@ -279,6 +287,10 @@ class ANI:
     def set_ghost_fold(self, d_owner, d_shift, nghost: int, stream=None):
         """ani_set_ghost_fold: device addresses of owner[nghost] (int64) and shift[nghost][3] (float64); None clears"""
         self._check(self._lib.ani_set_ghost_fold(self._h, d_owner, d_shift, int(nghost), stream))
+
+    def stage_ghost_fold(self, d_owner, d_shift, nghost: int):
+        """ani_stage_ghost_fold: the fold of the list the NEXT build_list* call builds (checked behind that build's synchronisation)"""
+        self._check(self._lib.ani_stage_ghost_fold(self._h, d_owner, d_shift, int(nghost)))
 
     def last_mlp_kernel(self) -> str:
         return self._lib.ani_last_mlp_kernel(self._h).decode()

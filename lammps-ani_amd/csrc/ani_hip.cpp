@@ -170,8 +170,18 @@ struct ani_handle {
   // one-pass list build (launch_nbr_onepass): rows of jraw_stride entries in jraw (0: dense segments), sized from the longest
   // list of the build before
   int jraw_stride = 0, nbr_cap_hint = 0, nbr_onepass = 1;
+  // the build in one kernel (launch_nbr_sorted_rows): jlist itself holds rows of jlist_row_stride entries, already grouped by
+  // species; the overflow word of that kernel is read behind rebuild()'s own synchronisation (0: dense segments, as ever)
+  int jlist_row_stride = 0, nbr_sorted_rows = 1, nbr_half_cells = 0;
   int* pinned_ints = nullptr;   // page-locked host words for small read-backs that ride on a later synchronisation
   DevBuf<int> nb_ovf;
+  DevBuf<float4> nb_xq;
+  // ghost fold handed over BEFORE the list it belongs to (ani_stage_ghost_fold): installed by the next list build, its check
+  // behind that build's synchronisation
+  const int64_t* stage_owner = nullptr;
+  const double* stage_shift = nullptr;
+  int stage_nghost = -1;
+  bool origin_from_box = false;   // ani_build_list*: the caller's bounding box gives the epoch's origin, no kernel
   // ghost fold of the epoch (ani_set_ghost_fold): maps of the caller + the chains of images made from them
   GhostFold fold;
   int fold_nghost = -1;      // -1: none installed (every list build clears it)
@@ -431,11 +441,12 @@ int specialize(ani_handle* h, int mask) {
 
 // (re)build everything that depends on the neighbour list: offsets, species buckets, activation arena.
 // d_species/d_ilist/d_numneigh/d_jlist already hold this epoch's list in the handle's own buffers.
+constexpr int kRebuildRowsOverflow = -1000;   // internal: the rows of launch_nbr_sorted_rows were too short
 int rebuild(ani_handle* h, hipStream_t st) {
   const HostModel& m = h->model;
   roctxMarkA("neighbor list rebuilt");   // src/ani_csrc/ani.cpp:128,215
   TraceRange tr("ani: list epoch set-up (offsets, species buckets, segment sort)");
-  h->need_origin = true;
+  h->need_origin = !h->origin_from_box;
   h->fold_nghost = -1;       // the maps belonged to the list before
   h->classes_valid = false;
   h->split_phase = 0;
@@ -452,18 +463,36 @@ int rebuild(ani_handle* h, hipStream_t st) {
   // every few steps must still be able to tell a capacity overflow from a stalled kernel (ani_debug_get: error_flags).  The
   // word travels to a page-locked host word without a synchronisation of its own: it is read behind the one the bucket
   // counts below need anyway.
-  if (!h->pinned_ints) HIP_TRY(h, hipHostMalloc((void**)&h->pinned_ints, sizeof(int) * 16, hipHostMallocDefault));
-  h->pinned_ints[0] = 0;
+  if (!h->pinned_ints) HIP_TRY(h, hipHostMalloc((void**)&h->pinned_ints, sizeof(int) * 32, hipHostMallocDefault));
+  h->pinned_ints[0] = h->pinned_ints[1] = h->pinned_ints[2] = 0;
   HIP_TRY(h, hipMemcpyAsync(&h->pinned_ints[0], h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(h, hipMemsetAsync(h->err_flag.p, 0, sizeof(int), st));
   HIP_TRY(h, h->row_of_atom.reserve((size_t)std::max(h->ntotal, 1)));
   PrepOut o{h->nbr_off.p, h->row_of_centre.p, h->centre_of_row.p, h->row_info.p, h->bucket_info.p, h->row_of_atom.p};
-  launch_prepare(h->species.p, h->ilist.p, h->numneigh.p, nlocal, h->ntotal, m.S, nrows_cap, o, st);
+  launch_prepare(h->species.p, h->ilist.p, h->numneigh.p, nlocal, h->ntotal, m.S, nrows_cap, o, st, h->jlist_row_stride);
+  if (h->jlist_row_stride) HIP_TRY(h, hipMemcpyAsync(&h->pinned_ints[1], h->nb_ovf.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  // a staged ghost fold: its chains are made here, its check rides on the synchronisation below
+  const bool fold_staged = h->stage_nghost >= 0 && h->stage_owner && h->use_single && h->stage_nghost == h->ntotal - nlocal;
+  if (fold_staged) {
+    HIP_TRY(h, h->fold_head.reserve((size_t)std::max(nlocal, 1)));
+    HIP_TRY(h, h->fold_next.reserve((size_t)std::max(h->stage_nghost, 1)));
+    HIP_TRY(h, h->fold_bad.reserve(1));
+    launch_ghost_chain(reinterpret_cast<const long long*>(h->stage_owner), h->stage_nghost, nlocal, h->fold_head.p, h->fold_next.p, h->fold_bad.p, st);
+    HIP_TRY(h, hipMemcpyAsync(&h->pinned_ints[2], h->fold_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
   int info[kBucketInfoInts];
   HIP_TRY(h, hipMemcpyAsync(info, h->bucket_info.p, sizeof(info), hipMemcpyDeviceToHost, st));
   HIP_TRY(h, hipStreamSynchronize(st));
   h->sticky_flags |= h->pinned_ints[0];   // the error word of the epoch before (copied above)
   HIP_TRY(h, take_launch_error());
+  if (h->jlist_row_stride && h->pinned_ints[1]) return kRebuildRowsOverflow;   // build_list fills dense segments instead
+  if (h->jlist_row_stride) h->npairs = info[2 * kMaxSpecies + 4];
+  if (fold_staged) {
+    if (h->pinned_ints[2]) { h->stage_nghost = -1; h->err = "ani_stage_ghost_fold: an owner index lies outside [0, nlocal)"; return ANI_ERR_ARG; }
+    h->fold.owner = reinterpret_cast<const long long*>(h->stage_owner); h->fold.shift = h->stage_shift; h->fold.nlocal = nlocal;
+    h->fold_nghost = h->stage_nghost;
+  }
+  h->stage_nghost = -1;
   if (info[2 * kMaxSpecies + 1]) { h->err = "an atom has a species outside the model's species list (or ilist holds an index outside [0, ntotal))"; return ANI_ERR_ARG; }
   for (int s = 0; s < m.S; s++) { h->count[s] = info[s]; h->row_start[s] = info[kMaxSpecies + s]; }
   h->nrows = info[2 * kMaxSpecies];
@@ -493,8 +522,9 @@ int rebuild(ani_handle* h, hipStream_t st) {
       }
     }
   }
-  // neighbour segments grouped by species: what lets the AEV kernels accumulate without atomics
-  launch_sort_jlist(h->species.p, h->nbr_off.p, h->numneigh.p, h->jraw.p, h->jlist.p, nlocal, m.S, info[2 * kMaxSpecies + 3], st, h->jraw_stride);
+  // neighbour segments grouped by species: what lets the AEV kernels accumulate without atomics (launch_nbr_sorted_rows
+  // leaves its rows that way)
+  if (!h->jlist_row_stride) launch_sort_jlist(h->species.p, h->nbr_off.p, h->numneigh.p, h->jraw.p, h->jlist.p, nlocal, m.S, info[2 * kMaxSpecies + 3], st, h->jraw_stride);
 
   const size_t stride = h->ap_run.aev_stride;
   if (!h->use_single) {
@@ -1377,7 +1407,8 @@ int ani_compute_full_device(ani_handle* h, int ntotal, int nlocal, const int* d_
     // (The 3/4 estimate of the host entry points saves LDS only; they repeat the step when it was too small.)
     h->ap.full_cap = h->ap_run.full_cap = 1;
     h->list_is_ours = false;
-    h->jraw_stride = 0;
+    h->jraw_stride = h->jlist_row_stride = 0;
+    h->origin_from_box = false;
     rc = rebuild(h, st);
     if (rc) return rc;
     h->have_list = true;
@@ -1493,13 +1524,14 @@ int build_list(ani_handle* h, int ntotal, int nlocal, const int* d_species, cons
   for (int k = 0; k < 3; k++) {
     const double len = hi[k] - lo[k];
     if (!(len > 0)) { h->err = "empty bounding box"; return ANI_ERR_ARG; }
-    int nc = (int)(len / cutneigh);
+    int nc = (int)(len / (h->nbr_half_cells ? 0.5 * cutneigh : cutneigh));
     nc = std::max(1, std::min(nc, 1024));
     g.lo[k] = lo[k]; g.inv[k] = nc / len; g.nc[k] = nc;
     ncell *= nc;
   }
   if (ncell > (1LL << 26)) { h->err = "bounding box too large for the cell grid"; return ANI_ERR_ARG; }
   g.ncell = (int)ncell;
+  g.reach = h->nbr_half_cells ? 2 : 1;
   h->have_list = false;
   h->ntotal = ntotal; h->nlocal = nlocal;
   HIP_TRY(h, h->nb_cell_id.reserve(ntotal));
@@ -1515,14 +1547,49 @@ int build_list(ani_handle* h, int ntotal, int nlocal, const int* d_species, cons
   NbrScratch s{h->nb_cell_id.p, h->nb_cell_count.p, h->nb_cell_start.p, h->nb_cursor.p, h->nb_order.p, h->nb_xs.p};
   if (d_species != h->species.p)
     HIP_TRY(h, hipMemcpyAsync(h->species.p, d_species, sizeof(int) * (size_t)ntotal, hipMemcpyDeviceToDevice, st));
-  launch_nbr_bin(d_x, ntotal, g, s, st);
-  // One pass where the longest list of the build before says how long a row can get (count and fill walk the same 27 cells
-  // with the same distance tests: 0.125 + 0.154 ms at 100 002 atoms, the pass into rows of a fixed capacity 0.16); the first
-  // build of a handle, and any build that overflows its rows, counts first and fills dense segments.
-  int total = 0, ovf = 0;
+  // the epoch's origin (the fp32 positions of the steps are relative to it): the middle of the caller's box, no kernel
+  if (!h->pinned_ints) HIP_TRY(h, hipHostMalloc((void**)&h->pinned_ints, sizeof(int) * 32, hipHostMallocDefault));
+  {
+    HIP_TRY(h, h->origin.reserve(3));
+    double* mid = reinterpret_cast<double*>(h->pinned_ints + 8);
+    for (int k = 0; k < 3; k++) mid[k] = 0.5 * (lo[k] + hi[k]);
+    HIP_TRY(h, hipMemcpyAsync(h->origin.p, mid, 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    h->origin_from_box = true;
+  }
+  h->list_is_ours = true;
+  h->jraw_stride = h->jlist_row_stride = 0;
+  // Rows of a fixed capacity where the longest list of the build before says how long a row can get; the first build of a
+  // handle, and any build that overflows its rows, counts first and fills dense segments (count and fill walk the same cells
+  // with the same distance tests: 0.125 + 0.154 ms at 100 002 atoms).
   const int cap = h->nbr_cap_hint > 0 ? round_up(h->nbr_cap_hint + h->nbr_cap_hint / 8 + 8, 8) : 0;
-  const bool onepass = h->nbr_onepass && cap > 0 && (long long)nlocal * cap < (1LL << 31);
-  h->jraw_stride = 0;
+  const bool rows_fit = h->nbr_onepass && cap > 0 && (long long)nlocal * cap < (1LL << 31);
+  const bool sorted_rows = rows_fit && h->nbr_sorted_rows && nbr_sorted_rows_supported(ntotal, h->model.S, cap);
+  if (sorted_rows) {
+    // search and species grouping in one kernel straight into jlist; pair count, overflow word, bucket counts and the check of
+    // a staged ghost fold all come back behind the ONE synchronisation of rebuild()
+    HIP_TRY(h, h->nb_xq.reserve((size_t)std::max(ntotal, 1)));
+    s.xq = h->nb_xq.p;
+    launch_nbr_bin(d_x, ntotal, g, s, st, h->species.p);
+    HIP_TRY(h, h->nb_ovf.reserve(1));
+    HIP_TRY(h, h->jlist.reserve((size_t)std::max(nlocal, 1) * cap));
+    launch_nbr_sorted_rows(nlocal, ntotal, g, s, cutneigh, h->model.S, cap, h->numneigh.p, h->ilist.p, h->jlist.p, h->nb_ovf.p, st);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, take_launch_error());
+    h->jlist_row_stride = cap;
+    rc = rebuild(h, st);
+    if (rc != kRebuildRowsOverflow) {
+      if (rc) return rc;
+      h->nbr_cap_hint = h->max_numneigh;
+      h->have_list = true;
+      if (out_npairs) *out_npairs = h->npairs;
+      return ANI_OK;
+    }
+    h->jlist_row_stride = 0;   // a row was too short: the bins stand, count and fill as below
+  } else {
+    launch_nbr_bin(d_x, ntotal, g, s, st);
+  }
+  int total = 0, ovf = 0;
+  const bool onepass = rows_fit && !sorted_rows;
   if (onepass) {
     HIP_TRY(h, h->nb_ovf.reserve(1));
     HIP_TRY(h, h->jraw.reserve((size_t)std::max(nlocal, 1) * cap));
@@ -1544,7 +1611,6 @@ int build_list(ani_handle* h, int ntotal, int nlocal, const int* d_species, cons
   }
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, take_launch_error());
-  h->list_is_ours = true;
   rc = rebuild(h, st);
   if (rc) return rc;
   h->nbr_cap_hint = h->max_numneigh;
@@ -1629,7 +1695,8 @@ int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
     HIP_TRY(h, hipMemcpyAsync(h->jraw.p, jlist, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice, st));
     h->have_list = false;
     h->list_is_ours = false;
-    h->jraw_stride = 0;
+    h->jraw_stride = h->jlist_row_stride = 0;
+    h->origin_from_box = false;
     rc = rebuild(h, st);
     if (rc) return rc;
     h->have_list = true;
@@ -1731,6 +1798,16 @@ int ani_set_ghost_fold(ani_handle* h, const int64_t* d_owner, const double* d_sh
   return ANI_OK;
 }
 
+int ani_stage_ghost_fold(ani_handle* h, const int64_t* d_owner, const double* d_shift, int nghost) {
+  if (!h) return ANI_ERR_ARG;
+  h->stage_owner = nullptr; h->stage_shift = nullptr; h->stage_nghost = -1;
+  if (!d_owner || nghost < 0) return ANI_OK;   // cleared
+  if (!h->use_single) { h->err = "ani_stage_ghost_fold: the fp64 kernels do not fold ghosts (use the exchange kernels)"; return ANI_ERR_ARG; }
+  if (!d_shift && nghost > 0) { h->err = "ani_stage_ghost_fold: null shift"; return ANI_ERR_ARG; }
+  h->stage_owner = d_owner; h->stage_shift = d_shift; h->stage_nghost = nghost;
+  return ANI_OK;
+}
+
 const char* ani_last_mlp_kernel(const ani_handle* h) { return h ? h->last_mlp_kernel : ""; }
 
 int ani_attach_comm(ani_handle* h, void* comm) {
@@ -1784,6 +1861,14 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   }
   if (strcmp(name, "nbr_onepass") == 0) {
     h->nbr_onepass = value != 0;
+    return ANI_OK;
+  }
+  if (strcmp(name, "nbr_sorted_rows") == 0) {
+    h->nbr_sorted_rows = value != 0;
+    return ANI_OK;
+  }
+  if (strcmp(name, "nbr_half_cells") == 0) {
+    h->nbr_half_cells = value != 0;
     return ANI_OK;
   }
   if (strcmp(name, "reuse_build_list_upload") == 0) {

@@ -12,7 +12,7 @@ namespace ani {
 constexpr int kRowTile = 128;   // AEV rows per GEMM block; species buckets are padded to this
 constexpr int kMaxRad = 256;    // per-centre capacity of the radial neighbour list held in LDS
 constexpr int kMaxAng = 96;     // per-centre capacity of the angular neighbour list held in LDS
-constexpr int kBucketInfoInts = 2 * kMaxSpecies + 4;
+constexpr int kBucketInfoInts = 2 * kMaxSpecies + 5;
 constexpr int kVirialSlots = 1024;  // rows of 9 doubles the waves of the AEV backward spread their virial sums over
 
 enum Epilogue { EPI_PLAIN = 0, EPI_CELU = 1, EPI_LAST = 2, EPI_BWD = 3 };
@@ -184,16 +184,16 @@ void launch_row_classes(const int4* row_info, const int* jlist, int nrows, int n
 
 // rebuild-time preparation: neighbour offsets, species buckets.  All outputs device arrays.
 struct PrepOut {
-  int* nbr_off;         // [nlocal+1] exclusive scan of numneigh
+  int* nbr_off;         // [nlocal+1] exclusive scan of numneigh (row_stride = 0) or ii * row_stride
   int* row_of_centre;   // [prepare_scratch_ints(nlocal)]: [nlocal] rows, then scratch
   int* centre_of_row;   // [nrows_cap] (-1 = padding)
   int4* row_info;       // [nrows_cap] per AEV row: {i, list begin, list length, ii}; i = -1 for padding rows
-  int* bucket_info;     // [kBucketInfoInts]: count[s], row_start[s], nrows, bad_species flag, max numneigh, species-present mask
+  int* bucket_info;     // [kBucketInfoInts]: count[s], row_start[s], nrows, bad_species flag, max numneigh, species-present mask, pairs
   int* row_of_atom;     // [ntotal] or NULL: the AEV row of an atom that is a centre, -1 for every other atom (ghosts)
 };
 size_t prepare_scratch_ints(int nlocal);   // size of PrepOut::row_of_centre (rows + scratch of the two kernels)
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
-                    const PrepOut& o, hipStream_t st);
+                    const PrepOut& o, hipStream_t st, int row_stride = 0);
 // 1 in *d_out unless every entry i -> j between two centres of the list has its mirror j -> i (ani_kernels_misc.hip); d_acc: [ntotal] scratch
 void launch_list_symmetry(const int* d_ilist, const int* d_nbr_off, const int* d_numneigh, const int* d_jraw, const int* d_row_of_atom,
                           int nlocal, int ntotal, unsigned* d_acc, int* d_out, hipStream_t st);
@@ -268,6 +268,7 @@ void launch_sort_jlist(const int* d_species, const int* d_nbr_off, const int* d_
 struct NbrGrid {
   double lo[3], inv[3];  // inv = nc / (hi - lo)
   int nc[3], ncell;
+  int reach = 1;         // cells to search either side: 1 for cells no smaller than the cutoff, 2 for half that edge
 };
 struct NbrScratch {
   int* cell_id;     // [ntotal]
@@ -276,8 +277,9 @@ struct NbrScratch {
   int* cursor;      // [ncell]
   int* order;       // [ntotal] atoms sorted by cell
   double* xs;       // [ntotal*3] positions in that order
+  float4* xq = nullptr;  // [ntotal] fp32 position relative to the grid origin + (atom | species << 28), same order (optional)
 };
-void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrScratch& s, hipStream_t st);
+void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrScratch& s, hipStream_t st, const int* d_species = nullptr);
 // numneigh[nlocal] and its exclusive scan nbr_off[nlocal+1]
 void launch_nbr_count(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int* d_numneigh,
                       int* d_nbr_off, hipStream_t st);
@@ -287,6 +289,10 @@ void launch_nbr_fill(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch&
 // one pass instead of launch_nbr_count + launch_nbr_fill: rows of `cap` entries, true counts, their scan, an overflow word
 void launch_nbr_onepass(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int cap, int* d_numneigh,
                         int* d_nbr_off, int* d_jrows, int* d_ilist, int* d_ovf, hipStream_t st);
+// search + species grouping in one kernel into rows of `cap` entries (bins from launch_nbr_bin with species)
+bool nbr_sorted_rows_supported(int ntotal, int S, int cap);
+void launch_nbr_sorted_rows(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int S, int cap,
+                            int* d_numneigh, int* d_ilist, int* d_jrows, int* d_ovf, hipStream_t st);
 
 // optional pairwise repulsion (ani_kernels_rep.hip)
 struct RepArgs {

@@ -134,7 +134,10 @@ __global__ __launch_bounds__(1024) void prepare_count_kernel(const int* __restri
     if (i0 + k < nlocal) o.nbr_off[i0 + k] = ex;
     ex += nn[k];
   }
-  if (threadIdx.x == 0) tot[0] = total;
+  if (threadIdx.x == 0) {
+    tot[0] = total;
+    if (total) atomicAdd(&o.bucket_info[2 * kMaxSpecies + 4], total);   // all pairs of the list (fits: the callers bound it by 2^31)
+  }
   if (vmax) atomicMax(&o.bucket_info[2 * kMaxSpecies + 2], vmax);
   // stable rank inside the species, chunk-relative
   for (int s = 0; s < S; s++) {
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(1024) void prepare_count_kernel(const int* __restri
 __global__ __launch_bounds__(256) void prepare_rows_kernel(const int* __restrict__ species, const int* __restrict__ ilist,
                                                             const int* __restrict__ numneigh, int nlocal, int ntotal, int S,
                                                             int nrows_cap, PrepOut o, const int* __restrict__ rank_in_species,
-                                                            const int* __restrict__ chunk_tot) {
+                                                            const int* __restrict__ chunk_tot, int row_stride) {
   __shared__ int row_start[kMaxSpecies + 1];
   __shared__ int before[kMaxSpecies + 1];   // totals of the chunks before this block's chunk: pairs, centres per species
   const int chunk = (blockIdx.x * blockDim.x) / kPrepChunk;   // kPrepChunk is a multiple of the block size
@@ -192,9 +195,11 @@ __global__ __launch_bounds__(256) void prepare_rows_kernel(const int* __restrict
     if (nlocal == 0 && ii == 0) o.nbr_off[0] = 0;
     return;
   }
-  const int off = before[0] + o.nbr_off[ii], len = numneigh[ii];
+  // dense segments, or rows of row_stride entries (the list built by launch_nbr_sorted_rows; ilist is the identity there)
+  const int len = numneigh[ii];
+  const int off = row_stride > 0 ? ii * row_stride : before[0] + o.nbr_off[ii];
   o.nbr_off[ii] = off;
-  if (ii == nlocal - 1) o.nbr_off[nlocal] = off + len;
+  if (ii == nlocal - 1) o.nbr_off[nlocal] = row_stride > 0 ? nlocal * row_stride : off + len;
   const int i = ilist[ii];
   const int sp = (i >= 0 && i < ntotal) ? species[i] : -1;   // a bad index was flagged by the first kernel: the caller stops
   if (sp < 0 || sp >= S) { o.row_of_centre[ii] = -1; return; }
@@ -212,7 +217,7 @@ size_t prepare_scratch_ints(int nlocal) {   // row_of_centre: [nlocal] rows, [nl
 }
 
 void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numneigh, int nlocal, int ntotal, int S, int nrows_cap,
-                    const PrepOut& o, hipStream_t st) {
+                    const PrepOut& o, hipStream_t st, int row_stride) {
   // row_of_centre is sized prepare_scratch_ints(nlocal) by the caller
   int* rank = o.row_of_centre + nlocal;
   int* chunk_tot = o.row_of_centre + 2 * (size_t)nlocal;
@@ -224,7 +229,7 @@ void launch_prepare(const int* d_species, const int* d_ilist, const int* d_numne
   hipLaunchKernelGGL(prepare_count_kernel, dim3(nchunks), dim3(1024), 0, st, d_species, d_ilist, d_numneigh, nlocal, ntotal, S, o,
                      rank, chunk_tot);
   hipLaunchKernelGGL(prepare_rows_kernel, dim3(nlocal > 0 ? (nlocal + 255) / 256 : 1), dim3(256), 0, st, d_species, d_ilist,
-                     d_numneigh, nlocal, ntotal, S, nrows_cap, o, rank, chunk_tot);
+                     d_numneigh, nlocal, ntotal, S, nrows_cap, o, rank, chunk_tot, row_stride);
 }
 
 // ---- is the list symmetric? ------------------------------------------------------------------------------------------

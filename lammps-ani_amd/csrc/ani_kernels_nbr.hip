@@ -139,6 +139,22 @@ __global__ void nbr_gather_kernel(const double* __restrict__ x, const int* __res
   xs[3 * p] = x[3 * a]; xs[3 * p + 1] = x[3 * a + 1]; xs[3 * p + 2] = x[3 * a + 2];
 }
 
+// the same, plus what the one-kernel build (nbr_search_sorted_kernel) reads per candidate in ONE 16-byte load: the position in
+// fp32 relative to the grid origin and, in the fourth word, the atom index with the species in the four bits above kIdxBits
+constexpr int kIdxBits = 28;
+constexpr unsigned kIdxMask = (1u << kIdxBits) - 1u;
+
+__global__ void nbr_gather_packed_kernel(const double* __restrict__ x, const int* __restrict__ order, const int* __restrict__ species,
+                                         int ntotal, NbrGrid g, double* __restrict__ xs, float4* __restrict__ xq) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ntotal) return;
+  const int a = order[p];
+  const double px = x[3 * a], py = x[3 * a + 1], pz = x[3 * a + 2];
+  xs[3 * p] = px; xs[3 * p + 1] = py; xs[3 * p + 2] = pz;
+  const unsigned w = (unsigned)a | (((unsigned)species[a] & 15u) << kIdxBits);
+  xq[p] = make_float4((float)(px - g.lo[0]), (float)(py - g.lo[1]), (float)(pz - g.lo[2]), __uint_as_float(w));
+}
+
 // kSearchLanes lanes per atom: the candidates of a cell range are taken kSearchLanes at a time (contiguous positions:
 // coalesced), hits are placed by a ballot over the group -- the order of a list is the serial order (cell ranges, then
 // sorted position), whatever the lane count.  One lane per atom left the chip latency-bound (2 waves per SIMD, a
@@ -164,13 +180,14 @@ __global__ __launch_bounds__(256) void nbr_search_kernel(const double* __restric
   const double xi = xs[3 * p], yi = xs[3 * p + 1], zi = xs[3 * p + 2];
   int cx, cy, cz;
   cell_coords(g, xi, yi, zi, cx, cy, cz);
-  const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < g.nc[0] - 1 ? cx + 1 : g.nc[0] - 1;
+  const int R = g.reach;
+  const int x0 = cx - R > 0 ? cx - R : 0, x1 = cx + R < g.nc[0] - 1 ? cx + R : g.nc[0] - 1;
   int n = 0;
   int* out = MODE == 1 ? jlist + nbr_off[i] : (MODE == 2 ? jlist + (size_t)i * cap : nullptr);
-  for (int dz = -1; dz <= 1; dz++) {
+  for (int dz = -R; dz <= R; dz++) {
     const int z = cz + dz;
     if (z < 0 || z >= g.nc[2]) continue;
-    for (int dy = -1; dy <= 1; dy++) {
+    for (int dy = -R; dy <= R; dy++) {
       const int y = cy + dy;
       if (y < 0 || y >= g.nc[1]) continue;
       const int rowc = (z * g.nc[1] + y) * g.nc[0];
@@ -198,6 +215,122 @@ __global__ __launch_bounds__(256) void nbr_search_kernel(const double* __restric
   }
 }
 
+// The list build in ONE kernel: search, and every centre's entries grouped by neighbour species (what sort_jlist_kernel does to a
+// caller's list), written to rows of `cap` entries at jrows[i * cap].  Sixteen lanes per centre as above.  Per candidate one
+// 16-byte load (nbr_gather_packed_kernel); the cutoff test runs in fp32 on positions relative to the grid origin and falls back
+// to the fp64 test of the kernels above -- rsq <= cutneighsq on the caller's doubles, as LAMMPS' npair full/bin -- whenever the
+// fp32 value lies within `band` of the cutoff, band being twice the worst rounding error of the fp32 value: the list is the
+// same set.  Hits are parked in LDS (one row per centre) in the serial order of the kernels above, counted per species, and
+// written out species by species, order kept inside a species: the result equals sort_jlist_kernel applied to the rows of
+// nbr_search_kernel<2>.  The cell ranges ((2R+1)^2 runs of 2R+1 x-adjacent cells) are fetched by the group's lanes side by
+// side and handed round with a shuffle instead of one dependent load pair per run.  R = g.reach: 1 for cells no smaller than
+// the cutoff, 2 for cells of half that edge (fewer candidates per hit: 0.59 of the volume).
+template <int R>
+__global__ __launch_bounds__(256) void nbr_search_sorted_kernel(const float4* __restrict__ xq, const double* __restrict__ xs,
+                                                                 const int* __restrict__ cell_start, NbrGrid g, int nlocal, int ntotal,
+                                                                 double cut2, float cutf, int S, int cap, int* __restrict__ numneigh,
+                                                                 int* __restrict__ ilist, int* __restrict__ jrows, int* __restrict__ ovf) {
+  extern __shared__ int rows_lds[];   // [16 centres][cap]
+  constexpr int L = kSearchLanes, W = 2 * R + 1, NRUN = W * W, RPL = (NRUN + L - 1) / L;
+  static_assert(L == 16, "group ballots below assume 16 lanes per centre");
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = (int)(t / L), l = threadIdx.x & (L - 1);
+  const int grp_shift = (threadIdx.x & 63) & ~(L - 1);
+  if (p >= ntotal) return;
+  const float4 me = xq[p];
+  const int i = (int)(__float_as_uint(me.w) & kIdxMask);
+  if (i >= nlocal) return;  // ghosts are neighbours only
+  const double xi = xs[3 * p], yi = xs[3 * p + 1], zi = xs[3 * p + 2];
+  int cx, cy, cz;
+  cell_coords(g, xi, yi, zi, cx, cy, cz);
+  const int x0 = cx - R > 0 ? cx - R : 0, x1 = cx + R < g.nc[0] - 1 ? cx + R : g.nc[0] - 1;
+  int rb[RPL], re[RPL];
+#pragma unroll
+  for (int k = 0; k < RPL; k++) {
+    const int r = l + L * k;
+    rb[k] = re[k] = 0;
+    const int z = cz + r / W - R, y = cy + r % W - R;
+    if (r < NRUN && z >= 0 && z < g.nc[2] && y >= 0 && y < g.nc[1]) {
+      const int rowc = (z * g.nc[1] + y) * g.nc[0];
+      rb[k] = cell_start[rowc + x0];
+      re[k] = cell_start[rowc + x1 + 1];
+    }
+  }
+  // |fp32 rsq - rsq| <= 2 (|dx|+|dy|+|dz|) M 2^-23 + rsq 2^-21 with M the largest coordinate in play: 3.5 cut M 2^-23 near the cutoff
+  const float cut2f = cutf * cutf;
+  const float M = fmaxf(fmaxf(fabsf(me.x), fabsf(me.y)), fabsf(me.z)) + 2.f * cutf;
+  const float band = 8.f * cutf * M * 1.1920929e-7f + 1e-6f * cut2f;
+  const float c_in = cut2f - band, c_out = cut2f + band;
+  int* row = rows_lds + (threadIdx.x >> 4) * cap;
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < RPL; k++) {
+    const int nrun = NRUN - L * k < L ? NRUN - L * k : L;
+    for (int r = 0; r < nrun; r++) {
+      const int beg = __shfl(rb[k], grp_shift + r), end = __shfl(re[k], grp_shift + r);
+      for (int q0 = beg; q0 < end; q0 += L) {
+        const int q = q0 + l;
+        bool hit = false;
+        unsigned e = 0;
+        if (q < end) {
+          const float4 c = xq[q];
+          const float dx = c.x - me.x, dy = c.y - me.y, dz = c.z - me.z;
+          const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          hit = r2 < c_in;
+          if (!hit && r2 <= c_out) {
+            const double ddx = xs[3 * q] - xi, ddy = xs[3 * q + 1] - yi, ddz = xs[3 * q + 2] - zi;
+            hit = ddx * ddx + ddy * ddy + ddz * ddz <= cut2;
+          }
+          hit = hit && q != p;
+          e = __float_as_uint(c.w);
+        }
+        const unsigned bits = (unsigned)(__ballot(hit) >> grp_shift) & 0xffffu;
+        if (hit) {
+          const int kk = n + __popc(bits & ((1u << l) - 1u));
+          if (kk < cap) row[kk] = (int)e;
+        }
+        n += __popc(bits);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int nn = n < cap ? n : cap;
+  int cnt[kMaxSpecies];
+#pragma unroll
+  for (int s = 0; s < kMaxSpecies; s++) cnt[s] = 0;
+  for (int k0 = 0; k0 < nn; k0 += L) {
+    const int sp = k0 + l < nn ? (int)((unsigned)row[k0 + l] >> kIdxBits) : -1;
+#pragma unroll
+    for (int s = 0; s < kMaxSpecies; s++)
+      if (s < S) cnt[s] += __popc((unsigned)(__ballot(sp == s) >> grp_shift) & 0xffffu);
+  }
+  int acc = 0;
+#pragma unroll
+  for (int s = 0; s < kMaxSpecies; s++) {
+    const int c = cnt[s];
+    cnt[s] = acc;   // from here on: where the next entry of species s goes
+    acc += c;
+  }
+  int* out = jrows + (size_t)i * cap;
+  for (int k0 = 0; k0 < nn; k0 += L) {
+    const unsigned e = k0 + l < nn ? (unsigned)row[k0 + l] : 0u;
+    const int sp = k0 + l < nn ? (int)(e >> kIdxBits) : -1;
+#pragma unroll
+    for (int s = 0; s < kMaxSpecies; s++)
+      if (s < S) {
+        const unsigned b = (unsigned)(__ballot(sp == s) >> grp_shift) & 0xffffu;
+        if (sp == s) out[cnt[s] + __popc(b & ((1u << l) - 1u))] = (int)(e & kIdxMask);
+        cnt[s] += __popc(b);
+      }
+  }
+  if (l == 0) {
+    numneigh[i] = n;
+    ilist[i] = i;
+    if (n > cap) *ovf = 1;
+  }
+}
+
 __global__ void iota_kernel(int* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = i;
@@ -205,7 +338,7 @@ __global__ void iota_kernel(int* __restrict__ out, int n) {
 
 }  // namespace
 
-void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrScratch& s, hipStream_t st) {
+void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrScratch& s, hipStream_t st, const int* d_species) {
   note_launch_error(hipMemsetAsync(s.cell_count, 0, sizeof(int) * (size_t)(g.ncell + 1), st));
   note_launch_error(hipMemsetAsync(s.cursor, 0, sizeof(int) * (size_t)g.ncell, st));
   if (ntotal <= 0) {
@@ -217,7 +350,8 @@ void launch_nbr_bin(const double* d_x, int ntotal, const NbrGrid& g, const NbrSc
   hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, s.cell_count, s.cell_start, g.ncell);
   hipLaunchKernelGGL(nbr_bin_fill_kernel, grid, block, 0, st, s.cell_id, s.cell_start, s.cursor, s.order, ntotal);
   hipLaunchKernelGGL(nbr_bin_sort_kernel, dim3((g.ncell + 3) / 4), block, 0, st, s.cell_start, s.order, g.ncell);
-  hipLaunchKernelGGL(nbr_gather_kernel, grid, block, 0, st, d_x, s.order, ntotal, s.xs);
+  if (d_species && s.xq) hipLaunchKernelGGL(nbr_gather_packed_kernel, grid, block, 0, st, d_x, s.order, d_species, ntotal, g, s.xs, s.xq);
+  else hipLaunchKernelGGL(nbr_gather_kernel, grid, block, 0, st, d_x, s.order, ntotal, s.xs);
 }
 
 namespace {
@@ -258,6 +392,25 @@ void launch_nbr_onepass(int nlocal, int ntotal, const NbrGrid& g, const NbrScrat
     hipLaunchKernelGGL(iota_kernel, dim3((nlocal + 255) / 256), dim3(256), 0, st, d_ilist, nlocal);
   }
   nbr_scan_offsets(nlocal, ntotal, s, d_numneigh, d_nbr_off, st);
+}
+
+// the whole build in one kernel (nbr_search_sorted_kernel): rows of `cap` entries grouped by species, true counts, identity
+// ilist, *d_ovf = 1 if a centre has more than cap neighbours.  The bins must come from launch_nbr_bin WITH species (s.xq).
+bool nbr_sorted_rows_supported(int ntotal, int S, int cap) {
+  return ntotal < (1 << kIdxBits) && S <= kMaxSpecies && S <= 16 && cap > 0 && (size_t)cap * 16 * sizeof(int) <= 64 * 1024;
+}
+void launch_nbr_sorted_rows(int nlocal, int ntotal, const NbrGrid& g, const NbrScratch& s, double cutneigh, int S, int cap,
+                            int* d_numneigh, int* d_ilist, int* d_jrows, int* d_ovf, hipStream_t st) {
+  note_launch_error(hipMemsetAsync(d_ovf, 0, sizeof(int), st));
+  if (nlocal <= 0 || ntotal <= 0) return;
+  const dim3 grid((unsigned)(((long long)ntotal * kSearchLanes + 255) / 256)), block(256);
+  const size_t lds = (size_t)cap * 16 * sizeof(int);
+  if (g.reach == 2)
+    hipLaunchKernelGGL(nbr_search_sorted_kernel<2>, grid, block, lds, st, s.xq, s.xs, s.cell_start, g, nlocal, ntotal, cutneigh * cutneigh,
+                       (float)cutneigh, S, cap, d_numneigh, d_ilist, d_jrows, d_ovf);
+  else
+    hipLaunchKernelGGL(nbr_search_sorted_kernel<1>, grid, block, lds, st, s.xq, s.xs, s.cell_start, g, nlocal, ntotal, cutneigh * cutneigh,
+                       (float)cutneigh, S, cap, d_numneigh, d_ilist, d_jrows, d_ovf);
 }
 
 }  // namespace ani

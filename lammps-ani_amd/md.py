@@ -211,11 +211,11 @@ class VerletRun:
         self._per_atom_factors()
         lo = dc.sub_lo - self.cutneigh - 0.25
         hi = dc.sub_hi + self.cutneigh + 0.25
+        # the fold goes in with the list: its check rides on the build's own synchronisation
+        self._fold = bool(self._want_fold and self.ani.use_single and not self._overlap)
+        if self._fold:
+            self.ani.stage_ghost_fold(dc.send_idx.data_ptr(), dc.send_shift.data_ptr(), ng)
         self.npairs = self.ani.build_list_device(self.ntotal, n, self.species.data_ptr(), self.x.data_ptr(), self.cutneigh, lo, hi, stream=st)
-        self._fold = False
-        if self._want_fold and self.ani.use_single and not self._overlap:
-            self.ani.set_ghost_fold(dc.send_idx.data_ptr(), dc.send_shift.data_ptr(), ng, stream=st)
-            self._fold = True
         self._xbuilt_buf.copy_(self.x[:n])
         self.x_built = self._xbuilt_buf
         self._check(md.ani_md_check(self._d2max.data_ptr(), self.ev.data_ptr(), self._chk_dev.data_ptr(), st))   # zeroes the maximum

@@ -293,3 +293,116 @@ def test_native_reneighbouring_equals_the_tensor_form(tmp_path, hip, monkeypatch
         for sa, sb in zip(a[0][1:], b[0][1:]):
             assert abs(sa[0] - sb[0]) <= 2 and abs(sa[1] - sb[1]) <= 40
         assert np.abs(a[1] - b[1]).max() < 1e-5 and abs(a[2] - b[2]) < 5e-3
+
+
+def _species_of(inp):
+    return np.asarray(inp.species)
+
+
+@pytest.mark.parametrize("half_cells", [0, 1], ids=["cells_cutoff", "cells_half_cutoff"])
+def test_one_kernel_build_equals_search_then_sort(half_cells, model_cache, hip):
+    """The build in one kernel (fp32 screening with the fp64 decision near the cutoff, rows grouped by species on the way out)
+    against the separate search and grouping kernels: the same entries in the same ORDER, centre by centre; grouped by species;
+    and the same sets as the harness's host build.  Second build of a handle: the first has no row capacity to go by."""
+    for sysm, grid, rank in ((hx.spatial_sort(hx.water_box(3000)), (1, 1, 1), 0), (hx.random_box(2500, 7, 31.0, seed=4), (2, 2, 2), 5),
+                             (hx.random_box(300, 7, 15.0, seed=5), (1, 1, 1), 0)):
+        inp = hx.decompose(sysm, grid=grid, rank=rank)
+        lists = {}
+        for rows in (0, 1):
+            ani = hip.ANI(model_cache("ani2x", 1, 11), 0)
+            ani.set_option("nbr_sorted_rows", rows)
+            ani.set_option("nbr_half_cells", half_cells if rows else 0)
+            for pad in (0.25, -3.0):
+                _build(ani, inp, pad=pad)
+                n, _, _ = _build(ani, inp, pad=pad)       # the build that has a capacity
+                assert n == inp.npairs
+                lists[(rows, pad)] = ani.debug_list(inp.nlocal)
+            ani.close()
+        sp = _species_of(inp)
+        for pad in (0.25, -3.0):
+            (nn0, jl0), (nn1, jl1) = lists[(0, pad)], lists[(1, pad)]
+            assert np.array_equal(nn0, inp.numneigh) and np.array_equal(nn1, inp.numneigh)
+            if not half_cells:
+                assert np.array_equal(jl0, jl1)            # same serial order inside every species group
+            off = np.concatenate([[0], np.cumsum(nn1)])
+            for i in range(inp.nlocal):
+                seg = jl1[off[i]:off[i + 1]]
+                assert (np.diff(sp[seg]) >= 0).all()       # grouped by species, ascending
+            for a, b in zip(_segments(nn1, jl1), _segments(inp.numneigh, inp.jlist)):
+                assert np.array_equal(a, b)
+
+
+def test_one_kernel_build_decides_pairs_at_the_cutoff_in_fp64(model_cache, hip):
+    """Pairs placed a few parts in 1e9 inside and outside the neighbour cutoff -- far inside the band in which the fp32 screening
+    cannot tell -- far from the origin of the grid (where fp32 is at its worst): the list must be the fp64 brute-force list."""
+    rng = np.random.default_rng(5)
+    cut, n = 7.1, 400
+    base = rng.uniform(0.0, 60.0, (n, 3)) + 400.0           # 400 A from the grid origin (lo is set far away below)
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    eps = rng.choice([-4e-9, -1e-9, 1e-9, 4e-9], size=n)
+    x = np.concatenate([base, base + u * (cut * (1.0 + eps))[:, None]])
+    ntotal = 2 * n
+    species = rng.integers(0, 7, ntotal).astype(np.int32)
+    d = x[:, None, :] - x[None, :, :]
+    r2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+    want = (r2 <= cut * cut) & ~np.eye(ntotal, dtype=bool)
+    near = np.abs(np.sqrt(r2) - cut) < 1e-7
+    assert near.sum() >= 2 * n                               # the constructed pairs, both directions
+    import torch
+    dev = torch.device("cuda:0")
+    xd = torch.as_tensor(x, device=dev).contiguous()
+    sd = torch.as_tensor(species, device=dev)
+    ani = hip.ANI(model_cache("ani2x", 1, 11), 0)
+    lo, hi = np.zeros(3), x.max(0) + 1.0
+    for rows in (0, 1):
+        ani.set_option("nbr_sorted_rows", rows)
+        for _ in range(2):
+            ani.build_list_device(ntotal, ntotal, sd.data_ptr(), xd.data_ptr(), cut, lo, hi)
+        torch.cuda.synchronize()
+        nn, jl = ani.debug_list(ntotal)
+        off = np.concatenate([[0], np.cumsum(nn)])
+        # pairs within one ulp of the fp64 sum may fall either way (fused multiply-adds on the device): none were constructed
+        for i in range(ntotal):
+            assert np.array_equal(np.sort(jl[off[i]:off[i + 1]]), np.nonzero(want[i])[0]), (rows, i)
+    ani.close()
+
+
+def test_one_kernel_build_falls_back_when_a_row_overflows(model_cache, hip):
+    """Rows sized from a sparse system, then a dense one through the same handle: the overflow word sends the build to the
+    count-and-fill path, and the list is still the host list; the build after that has rows again."""
+    sparse = hx.decompose(hx.random_box(600, 7, 40.0, seed=2))
+    dense = hx.decompose(hx.random_box(1200, 7, 20.0, seed=3))
+    assert dense.numneigh.max() > 2 * sparse.numneigh.max() + 16
+    ani = hip.ANI(model_cache("ani2x", 1, 11), 0)
+    _build(ani, sparse)
+    _build(ani, sparse)
+    for _ in range(2):
+        n, _, _ = _build(ani, dense)
+        assert n == dense.npairs
+        nn, jl = ani.debug_list(dense.nlocal)
+        assert np.array_equal(nn, dense.numneigh)
+        for a, b in zip(_segments(nn, jl), _segments(dense.numneigh, dense.jlist)):
+            assert np.array_equal(a, b)
+    ani.close()
+
+
+def test_staged_ghost_fold_is_checked_with_the_list(model_cache, hip):
+    import torch
+    inp = hx.decompose(hx.spatial_sort(hx.water_box(900)))
+    ani = hip.ANI(model_cache("ani2x", 1, 11), 0)
+    dev = torch.device("cuda:0")
+    ng = inp.ntotal - inp.nlocal
+    owner = torch.as_tensor(inp.owner_lidx.astype(np.int64), device=dev)
+    shift = torch.zeros((ng, 3), dtype=torch.float64, device=dev)
+    bad = owner.clone()
+    bad[ng // 2] = inp.nlocal + 5
+    for _ in range(2):                                       # both build paths
+        ani.stage_ghost_fold(bad.data_ptr(), shift.data_ptr(), ng)
+        with pytest.raises(hip.AniError, match="owner index"):
+            _build(ani, inp)
+    ani.stage_ghost_fold(owner.data_ptr(), shift.data_ptr(), ng)
+    _build(ani, inp)
+    ani.stage_ghost_fold(owner.data_ptr(), shift.data_ptr(), ng + 1)   # not this list's ghost count: dropped, no error
+    _build(ani, inp)
+    ani.close()
