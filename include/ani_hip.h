@@ -253,6 +253,10 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *     launch, each wave on the centre it is about to featurise, instead of as a kernel of its own in front of it; 0 = two
  *     kernels.  Same results; candidate lists longer than 256 entries and AEV shapes off the fast path take the two kernels
  *     whatever the option says.
+ *   "out_force_accumulate" (default 0; the LAMMPS adapter turns it on where it adds out_force to atom->f as it is): ani_compute_full
+ *     / ani_compute_half ADD the forces into out_force instead of overwriting it -- rows [0, nlocal) with a communicator attached
+ *     (the ghost rows have gone home on the device), all ntotal rows otherwise -- through a page-locked buffer of the library, in
+ *     chunks, the additions of one chunk running beside the copy of the next.  Nothing is added on a call that returns an error.
  *   "nbr_sorted_rows" (default 1): ani_build_list* searches the cells and groups every centre's neighbours by species in ONE kernel,
  *     into rows of a capacity taken from the longest list of the build before (a build that overflows its rows, and the first one
  *     of a handle, counts and fills dense segments instead); ani_debug_list then returns row offsets i * capacity.  0 = separate

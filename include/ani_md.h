@@ -41,6 +41,8 @@ int ani_md_forward_ghosts(double* x, const int64_t* owner, const double* shift, 
 
 /* the pair style's reverse communication on one rank:  f[owner[g]] += f[nlocal + g] */
 int ani_md_reverse_ghosts(double* f, const int64_t* owner, int nlocal, int nghost, void* stream);
+/* the same for a ghost block that is not in message order:  f[owner[g]] += f[nlocal + ghost_of[g]]  (ghost_of NULL: as above) */
+int ani_md_reverse_ghosts_ordered(double* f, const int64_t* owner, const int64_t* ghost_of, int nlocal, int nghost, void* stream);
 
 /* Several ranks: the two halves of the same exchanges around the all-to-all.
  * pack:    out[s] = x[owner[s]] + shift[s]   for the nsend atoms this rank sends (its message buffer, [nsend][3])

@@ -117,6 +117,7 @@ def lib():
         L.ani_md_check.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ani_md_forward_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ani_md_reverse_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ani_md_reverse_ghosts_ordered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ani_md_pack_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ani_md_unpack_reverse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         # include/ani_comm.h
@@ -181,13 +182,15 @@ class ANI:
         if rc != 0:
             raise AniError(f"libani_hip error {rc}: {self._lib.ani_last_error(self._h).decode()}")
 
-    def compute(self, inp, ago: int = 0, eflag_atom: bool = True, vflag: bool = True):
-        """Host-pointer entry points with a harness.RankInput (full or half list).  Returns a dict like the oracle's."""
+    def compute(self, inp, ago: int = 0, eflag_atom: bool = True, vflag: bool = True, force_into=None):
+        """Host-pointer entry points with a harness.RankInput (full or half list).  Returns a dict like the oracle's.
+        force_into: a C-contiguous float64 [ntotal, 3] array handed over as out_force (option out_force_accumulate adds into it)."""
         nt, nl = inp.ntotal, inp.nlocal
         species = np.ascontiguousarray(inp.species, dtype=np.int64)
         x = np.ascontiguousarray(inp.x, dtype=np.float64)
         e = np.zeros(1)
-        f = np.full((nt, 3), np.nan)
+        f = np.full((nt, 3), np.nan) if force_into is None else force_into
+        assert f.dtype == np.float64 and f.shape == (nt, 3) and f.flags.c_contiguous
         ea = np.zeros(nl)
         vir = np.zeros(9)
         if inp.half:

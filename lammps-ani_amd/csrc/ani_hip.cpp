@@ -22,6 +22,8 @@ static inline void roctxMarkA(const char*) {}
 #endif
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -59,7 +61,12 @@ struct DevBuf {
     hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
     if (e != hipSuccess) { cap = 0; return e; }
     cap = want;
-    if (zero) e = hipMemset(p, 0, want * sizeof(T));
+    // hipMemset on device memory runs on the null stream and may return before it has run; the handle's work is on
+    // non-blocking streams, which do not wait for the null stream: wait here (allocation time only)
+    if (zero) {
+      e = hipMemset(p, 0, want * sizeof(T));
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    }
     return e;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -110,8 +117,9 @@ inline MlpArith planes_arith(int i) { return i == 0 ? MLP_BF16X3 : MLP_F16X2; }
 
 struct ani_handle {
   HostModel model;
-  AevParams ap;       // the model's full AEV layout
-  AevParams ap_run;   // the layout the kernels run with this epoch: ap restricted to the species present
+  AevParams ap{};       // the model's full AEV layout
+  AevParams ap_run{};   // the layout the kernels run with this epoch: ap restricted to the species present (set by specialize();
+                        // value-initialised: the entry points look at ap_run.full_cap before the first epoch exists)
   SpeciesMap cmap{};  // species -> index among the species present
   int active_mask = -1;
   bool prune = true;  // ani_set_option("prune_absent_species")
@@ -173,6 +181,7 @@ struct ani_handle {
   // the build in one kernel (launch_nbr_sorted_rows): jlist itself holds rows of jlist_row_stride entries, already grouped by
   // species; the overflow word of that kernel is read behind rebuild()'s own synchronisation (0: dense segments, as ever)
   int jlist_row_stride = 0, nbr_sorted_rows = 1, nbr_half_cells = 0;
+  double* pinned_ev = nullptr;  // page-locked {energy, virial[9], error word} of a host-pointer step (launch_step_tail)
   int* pinned_ints = nullptr;   // page-locked host words for small read-backs that ride on a later synchronisation
   DevBuf<int> nb_ovf;
   DevBuf<float4> nb_xq;
@@ -208,6 +217,16 @@ struct ani_handle {
   // host staging for the host-pointer entry points
   std::vector<int> h_species32;
   int reuse_upload = 0;               // ani_set_option("reuse_build_list_upload")
+  // ani_set_option("out_force_accumulate"): the host entry points ADD the forces into out_force, chunk by chunk through a
+  // page-locked buffer of the library, the additions of one chunk beside the copy of the next
+  int out_force_accumulate = 0;
+  double* stage_force = nullptr;
+  size_t stage_force_cap = 0;
+  static constexpr int kForceChunks = 16;
+  unsigned* stage_flags = nullptr;          // page-locked: chunk c of the step has landed when stage_flags[c] == copy_epoch
+  DevBuf<unsigned long long> copy_ctr;      // workgroups through with chunk c, over all steps (launch_copy_out)
+  unsigned copy_epoch = 0;
+  unsigned long long host_step = 0;         // stamp of the host-pointer steps (launch_step_tail)
   const double* x64_from = nullptr;   // ani_build_list has just uploaded these coordinates into x64: the step that follows reuses them
   std::vector<int> h_half_num, h_half_j;
 
@@ -441,6 +460,7 @@ int specialize(ani_handle* h, int mask) {
 
 // (re)build everything that depends on the neighbour list: offsets, species buckets, activation arena.
 // d_species/d_ilist/d_numneigh/d_jlist already hold this epoch's list in the handle's own buffers.
+constexpr int kCopyOutBlocks = 32;   // workgroups of launch_copy_out: enough stores in flight for the link, few enough to finish chunks in order
 constexpr int kRebuildRowsOverflow = -1000;   // internal: the rows of launch_nbr_sorted_rows were too short
 int rebuild(ani_handle* h, hipStream_t st) {
   const HostModel& m = h->model;
@@ -1247,30 +1267,81 @@ int check_args(ani_handle* h, int ntotal, int nlocal, long long npairs, int ago)
   return ANI_OK;
 }
 
+// spin on a word the device writes into page-locked host memory; false after 5 s (a stalled device)
+template <typename T>
+bool wait_host_word(const volatile T* w, T want) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    for (int k = 0; k < 512; k++) {
+      if (*w == want) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return true;
+      }
+      __builtin_ia32_pause();
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) return false;
+  }
+}
+
 int finish_host(ani_handle* h, int ntotal, int nlocal, int eflag_atom, int vflag, double* out_energy, double* out_force,
                 double* out_atomic_energies, double* out_virial) {
   hipStream_t st = h->stream;
-  double ev[10];
-  int flag = 0;
-  HIP_TRY(h, hipMemcpyAsync(ev, h->ev.p, sizeof(ev), hipMemcpyDeviceToHost, st));
-  HIP_TRY(h, hipMemcpyAsync(&flag, h->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (!h->pinned_ev) {
+    HIP_TRY(h, hipHostMalloc((void**)&h->pinned_ev, sizeof(double) * 16, hipHostMallocDefault));
+    memset(h->pinned_ev, 0, sizeof(double) * 16);
+  }
+  const double* ev = h->pinned_ev;
+  const double stamp = (double)(++h->host_step);
+  launch_step_tail(h->ev.p, h->err_flag.p, h->pinned_ev, stamp, st);
+  const bool accumulate = h->out_force_accumulate && out_force;
+  const size_t rows = h->comm ? (size_t)nlocal : (size_t)ntotal;   // with a communicator the ghost rows have gone home on the device
   if (h->comm) {
     // the pair style's reverse communication, on the device: ghost rows -> their owners' rows (here or on a peer)
     if (ani_comm_reverse(h->comm, h->f64.p, nlocal, st) != ANI_OK) {
       h->err = std::string("ani_comm_reverse: ") + ani_comm_last_error(h->comm);
       return ANI_ERR_DEVICE;
     }
-    if (out_force) {
-      HIP_TRY(h, hipMemcpyAsync(out_force, h->f64.p, sizeof(double) * 3 * (size_t)nlocal, hipMemcpyDeviceToHost, st));
-      memset(out_force + 3 * (size_t)nlocal, 0, sizeof(double) * 3 * (size_t)(ntotal - nlocal));
+  }
+  // Accumulating: the forces come over by a kernel that writes page-locked host memory chunk after chunk and announces every
+  // chunk with a word (launch_copy_out); the additions of chunk c run while chunk c + 1 is on its way, and nothing waits for a
+  // copy-engine command (each costs ~15 us of gap to its neighbours on this platform).  ANI_FORCE_DMA=1: one copy, then add.
+  constexpr int kChunks = ani_handle::kForceChunks;
+  const bool polled = accumulate && rows >= 4096 && !getenv("ANI_FORCE_DMA");
+  if (accumulate) {
+    if (h->stage_force_cap < 3 * rows) {
+      if (h->stage_force) HIP_TRY(h, hipHostFree(h->stage_force));
+      h->stage_force = nullptr;
+      h->stage_force_cap = 3 * rows + 3 * rows / 2 + 64;
+      HIP_TRY(h, hipHostMalloc((void**)&h->stage_force, h->stage_force_cap * sizeof(double), hipHostMallocDefault));
+    }
+    if (polled) {
+      if (!h->stage_flags) {
+        HIP_TRY(h, hipHostMalloc((void**)&h->stage_flags, sizeof(unsigned) * kChunks, hipHostMallocDefault));
+        memset(h->stage_flags, 0, sizeof(unsigned) * kChunks);
+        HIP_TRY(h, h->copy_ctr.reserve(kChunks, true));
+      }
+      h->copy_epoch++;
+      launch_copy_out(h->f64.p, h->stage_force, (long long)(3 * rows), kChunks, h->copy_ctr.p, h->stage_flags, h->copy_epoch,
+                      kCopyOutBlocks, st);
+    } else {
+      HIP_TRY(h, hipMemcpyAsync(h->stage_force, h->f64.p, sizeof(double) * 3 * rows, hipMemcpyDeviceToHost, st));
     }
   } else if (out_force) {
-    HIP_TRY(h, hipMemcpyAsync(out_force, h->f64.p, sizeof(double) * 3 * (size_t)ntotal, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(out_force, h->f64.p, sizeof(double) * 3 * rows, hipMemcpyDeviceToHost, st));
+    if (rows < (size_t)ntotal) memset(out_force + 3 * rows, 0, sizeof(double) * 3 * ((size_t)ntotal - rows));
   }
   if (eflag_atom && out_atomic_energies)
     HIP_TRY(h, hipMemcpyAsync(out_atomic_energies, h->eatom.p, sizeof(double) * (size_t)nlocal, hipMemcpyDeviceToHost, st));
-  HIP_TRY(h, hipStreamSynchronize(st));
+  HIP_TRY(h, hipGetLastError());
+  if (polled) {
+    // the error word first: nothing may be added on a step that is going to be repeated or reported
+    if (!wait_host_word(&h->pinned_ev[11], stamp)) { h->err = "the device did not finish the step within 5 s"; return ANI_ERR_DEVICE; }
+  } else {
+    HIP_TRY(h, hipStreamSynchronize(st));
+  }
+  const int flag = (int)ev[10];
   if (flag) {
+    HIP_TRY(h, hipStreamSynchronize(st));   // a copy-out in flight lands in the staging buffer only
     HIP_TRY(h, hipMemsetAsync(h->err_flag.p, 0, sizeof(int), st));
     h->sticky_flags |= flag;
     if (flag & 2) {
@@ -1282,6 +1353,21 @@ int finish_host(ani_handle* h, int ntotal, int nlocal, int eflag_atom, int vflag
     h->err = "an atom has more neighbours inside the radial/angular cutoff than the kernels' LDS capacity (radial: the "
              "longest list, or 3/4 of it unless option full_radial_capacity is set; angular: " + std::to_string(kMaxAng) + ")";
     return ANI_ERR_CAPACITY;
+  }
+  if (accumulate) {
+    const double* __restrict__ src = h->stage_force;
+    double* __restrict__ dst = out_force;
+    const long long n = (long long)(3 * rows);
+    if (polled) {
+      for (int c = 0; c < kChunks; c++) {
+        if (!wait_host_word(&h->stage_flags[c], h->copy_epoch)) { h->err = "the device did not deliver the forces within 5 s"; return ANI_ERR_DEVICE; }
+        const long long a = (n * c / kChunks) & ~1LL, b = c + 1 == kChunks ? n : ((n * (c + 1) / kChunks) & ~1LL);   // as copy_out_kernel
+        for (long long k = a; k < b; k++) dst[k] += src[k];
+      }
+      HIP_TRY(h, hipStreamSynchronize(st));   // the kernel has delivered everything: this returns at once (per-atom energies, if any)
+    } else {
+      for (long long k = 0; k < n; k++) dst[k] += src[k];
+    }
   }
   if (out_energy) *out_energy = ev[0];
   if (vflag && out_virial) memcpy(out_virial, ev + 1, sizeof(double) * 9);
@@ -1334,6 +1420,10 @@ void ani_destroy(ani_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->pinned_ints) { (void)hipHostFree(h->pinned_ints); h->pinned_ints = nullptr; }
+  if (h->stage_force) { (void)hipHostFree(h->stage_force); h->stage_force = nullptr; }
+  if (h->pinned_ev) { (void)hipHostFree(h->pinned_ev); h->pinned_ev = nullptr; }
+  if (h->stage_flags) { (void)hipHostFree(h->stage_flags); h->stage_flags = nullptr; }
+  h->copy_ctr.release();
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   if (h->ev_mlp) (void)hipEventDestroy(h->ev_mlp);
   if (h->ev_side) (void)hipEventDestroy(h->ev_side);
@@ -1360,7 +1450,7 @@ void ani_destroy(ani_handle* h) {
     if (n.b_out64) (void)hipFree(n.b_out64);
   }
   h->species.release(); h->ilist.release(); h->numneigh.release(); h->jlist.release(); h->jraw.release(); h->nbr_off.release();
-  h->fold_head.release(); h->fold_next.release(); h->fold_bad.release(); h->nb_ovf.release(); h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release(); h->row_ctr.release(); h->row_of_atom.release();
+  h->fold_head.release(); h->fold_next.release(); h->fold_bad.release(); h->nb_ovf.release(); h->nb_xq.release(); h->row_of_centre.release(); h->centre_of_row.release(); h->bucket_info.release(); h->err_flag.release(); h->row_ctr.release(); h->row_of_atom.release();
   h->xyzs.release(); h->cl_xyz.release(); h->cl_hdr.release(); h->cl_j.release(); h->row_info.release(); h->row_flag.release(); h->row_list.release(); h->row_count.release(); h->x64.release(); h->f64.release(); h->ev.release(); h->eatom.release(); h->origin.release();
   h->rep_tables.release(); h->erep.release();
   h->nb_cell_id.release(); h->nb_cell_count.release(); h->nb_cell_start.release(); h->nb_cursor.release(); h->nb_order.release(); h->nb_xs.release();
@@ -1667,7 +1757,7 @@ int ani_compute_full(ani_handle* h, int ntotal, int nlocal, const int64_t* speci
   if (!coordinates || !out_force || !out_energy) { h->err = "null pointer argument"; return ANI_ERR_ARG; }
   HIP_TRY(h, hipSetDevice(h->device));
   hipStream_t st = h->stream;
-  if (h->comm && h->use_cuaev && !h->ap_run.full_cap) {
+  if (h->comm && h->use_cuaev && !(h->ap.full_cap && h->ap_run.full_cap)) {
     // With a communicator attached the step ends in a matched send / receive with every peer (finish_host), posted before
     // the capacity word is read.  The retry below would post a SECOND exchange on this rank alone: its peers have added the
     // overflowed step's ghost forces already and pair the extra message with their next step (forces one step stale, or a
@@ -1861,6 +1951,10 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
   }
   if (strcmp(name, "nbr_onepass") == 0) {
     h->nbr_onepass = value != 0;
+    return ANI_OK;
+  }
+  if (strcmp(name, "out_force_accumulate") == 0) {
+    h->out_force_accumulate = value != 0;
     return ANI_OK;
   }
   if (strcmp(name, "nbr_sorted_rows") == 0) {

@@ -182,6 +182,12 @@ void launch_pack(const double* d_x, const int* d_species, int i0, int i1, const 
 // the other rows, ascending.  flag: scratch, [nrows]
 void launch_row_classes(const int4* row_info, const int* jlist, int nrows, int nlocal, int* flag, int* list, int* count, hipStream_t st);
 
+// {energy, virial[9], error word, stamp} of a step -> host_out[12] (page-locked, device-visible host memory)
+void launch_step_tail(const double* d_ev, const int* d_flag, double* host_out, double stamp, hipStream_t st);
+// d_f[n] -> host[n] (page-locked) in nchunks chunks, host_flags[c] = epoch once chunk c has landed; d_ctr[nchunks] zeroed once
+void launch_copy_out(const double* d_f, double* host, long long n, int nchunks, unsigned long long* d_ctr, unsigned* host_flags,
+                     unsigned epoch, int nblocks, hipStream_t st);
+
 // rebuild-time preparation: neighbour offsets, species buckets.  All outputs device arrays.
 struct PrepOut {
   int* nbr_off;         // [nlocal+1] exclusive scan of numneigh (row_stride = 0) or ii * row_stride

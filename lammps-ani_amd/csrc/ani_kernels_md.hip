@@ -143,6 +143,15 @@ __global__ __launch_bounds__(256) void reverse_ghosts_kernel(double* __restrict_
   atomicAdd(&f[3 * owner[g] + k], f[3 * (size_t)nlocal + t]);
 }
 
+// the same with the ghost block in the caller's order: message slot g is ghost ghost_of[g]
+__global__ __launch_bounds__(256) void reverse_ghosts_ordered_kernel(double* __restrict__ f, const long long* __restrict__ owner,
+                                                                     const long long* __restrict__ ghost_of, int nlocal, int nghost) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * nghost) return;
+  const int g = t / 3, k = t - 3 * g;
+  atomicAdd(&f[3 * owner[g] + k], f[3 * ((size_t)nlocal + (size_t)ghost_of[g]) + k]);
+}
+
 // rows[k] = src[idx[k]] (gather) / dst[idx[k]] = rows[k] (scatter): three doubles per row
 __global__ __launch_bounds__(256) void gather_rows_kernel(const double* __restrict__ src, const long long* __restrict__ idx, int n,
                                                           double* __restrict__ out) {
@@ -324,6 +333,14 @@ int ani_md_reverse_ghosts(double* f, const int64_t* owner, int nlocal, int nghos
   if (nghost <= 0) return 0;
   hipLaunchKernelGGL(reverse_ghosts_kernel, dim3((3 * nghost + 255) / 256), dim3(256), 0, (hipStream_t)stream, f,
                      reinterpret_cast<const long long*>(owner), nlocal, nghost);
+  return (int)hipGetLastError();
+}
+
+int ani_md_reverse_ghosts_ordered(double* f, const int64_t* owner, const int64_t* ghost_of, int nlocal, int nghost, void* stream) {
+  if (nghost <= 0) return 0;
+  if (!ghost_of) return ani_md_reverse_ghosts(f, owner, nlocal, nghost, stream);
+  hipLaunchKernelGGL(reverse_ghosts_ordered_kernel, dim3((3 * nghost + 255) / 256), dim3(256), 0, (hipStream_t)stream, f,
+                     reinterpret_cast<const long long*>(owner), reinterpret_cast<const long long*>(ghost_of), nlocal, nghost);
   return (int)hipGetLastError();
 }
 

@@ -97,6 +97,53 @@ void launch_ghost_chain(const long long* d_owner, int nghost, int nlocal, int* d
   if (nghost > 0) hipLaunchKernelGGL(ghost_chain_kernel, dim3((nghost + 255) / 256), dim3(256), 0, st, d_owner, nghost, nlocal, d_head, d_next, d_bad);
 }
 
+// energy, virial and the error word of a step to page-locked host memory in ONE small kernel: two hipMemcpyAsync into the
+// caller's stack cost a staging copy each and ~20 us of gaps between copy-engine commands and kernels (100 002 atoms)
+__global__ void step_tail_kernel(const double* __restrict__ ev, const int* __restrict__ flag, volatile double* __restrict__ host_out,
+                                 double stamp) {
+  const int t = threadIdx.x;
+  if (t < 10) host_out[t] = ev[t];
+  if (t == 10) host_out[10] = (double)*flag;
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) { host_out[11] = stamp; __threadfence_system(); }   // a host that polls sees the stamp behind the values
+}
+void launch_step_tail(const double* d_ev, const int* d_flag, double* host_out, double stamp, hipStream_t st) {
+  hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(64), 0, st, d_ev, d_flag, host_out, stamp);
+}
+
+// Forces to page-locked host memory by a kernel, chunk after chunk, each chunk announced by a word the host polls: the host adds
+// chunk c into the caller's array while chunk c + 1 is on its way (finish_host, option out_force_accumulate).  A few workgroups
+// walk the chunks together so that they complete in order; the last workgroup to finish a chunk (device counter, which only
+// ever grows: epoch * gridDim.x when everybody is through) writes the chunk's word.  Every thread fences its stores system-wide
+// before the workgroup reports, so the word is behind the data.
+__global__ __launch_bounds__(256) void copy_out_kernel(const double* __restrict__ f, double* __restrict__ host, long long n, int nchunks,
+                                                       unsigned long long* __restrict__ ctr, volatile unsigned* __restrict__ host_flags,
+                                                       unsigned epoch) {
+  const double2* __restrict__ f2 = reinterpret_cast<const double2*>(f);
+  double2* __restrict__ h2 = reinterpret_cast<double2*>(host);
+  for (int c = 0; c < nchunks; c++) {
+    const long long a = (n * c / nchunks) & ~1LL, b = c + 1 == nchunks ? n : ((n * (c + 1) / nchunks) & ~1LL);
+    const long long len2 = (b - a) >> 1;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < len2; k += (long long)gridDim.x * blockDim.x)
+      h2[(a >> 1) + k] = f2[(a >> 1) + k];
+    if (((b - a) & 1) && blockIdx.x == 0 && threadIdx.x == 0) host[b - 1] = f[b - 1];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long done = atomicAdd(&ctr[c], 1ULL);
+      if (done + 1 == (unsigned long long)epoch * gridDim.x) {
+        host_flags[c] = epoch;
+        __threadfence_system();
+      }
+    }
+  }
+}
+void launch_copy_out(const double* d_f, double* host, long long n, int nchunks, unsigned long long* d_ctr, unsigned* host_flags,
+                     unsigned epoch, int nblocks, hipStream_t st) {
+  hipLaunchKernelGGL(copy_out_kernel, dim3(nblocks), dim3(256), 0, st, d_f, host, n, nchunks, d_ctr, host_flags, epoch);
+}
+
 // ---- rebuild-time preparation ------------------------------------------------------------------------
 // Two kernels over chunks of kPrepChunk centres.  The first scans, inside every chunk, the list lengths (-> offsets
 // relative to the chunk) and the species flags (-> stable rank of a centre among the centres of its species in the

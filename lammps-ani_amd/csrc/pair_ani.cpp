@@ -113,6 +113,7 @@ void PairANI::create_model() {
                             use_single ? 1 : 0, &ani);
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(nullptr));
   if (profiling) ani_set_option(ani, "profiling", 1);
+  direct_add = false;
   ani_set_option(ani, "reuse_build_list_upload", 1);   // devlist: ani_build_list and the step that follows see the same atom->x
   if (use_rccl) {
     // one RCCL communicator over the ranks of `world`: rank 0 makes the id, MPI carries it (the only MPI traffic of this path
@@ -290,7 +291,16 @@ void PairANI::compute(int eflag, int vflag) {
 
   if (use_rccl && ago == 0) build_rccl_maps(nlocal, atom->nghost);
 
-  grow_out_force((size_t)ntotal * 3);
+  // Where nothing reads the raw result before it is added to atom->f (rcclcomm: the ghost rows have gone home on the device;
+  // newton on: LAMMPS reverse-communicates f itself) the library adds it into f directly, chunk by chunk beside its own copies
+  // (option out_force_accumulate).  atom->f is one block in LAMMPS (memory->create); anything else keeps the buffer.
+  const bool direct = (use_rccl || force->newton) && ntotal > 0 && f[ntotal - 1] == f[0] + 3 * (size_t)(ntotal - 1);
+  if (direct != direct_add) {
+    ani_set_option(ani, "out_force_accumulate", direct ? 1 : 0);
+    direct_add = direct;
+  }
+  if (!direct) grow_out_force((size_t)ntotal * 3);
+  double* const fout = direct ? &f[0][0] : out_force;
   if (ago == 0 && pin_host && !x_registered && ntotal > 0 && atom->nmax >= ntotal &&
       ani_host_register(&x[0][0], sizeof(double) * 3 * (size_t)atom->nmax) == ANI_OK) {
     x_registered = &x[0][0];
@@ -306,17 +316,17 @@ void PairANI::compute(int eflag, int vflag) {
   int rc;
   if (use_devlist) {
     rc = ntotal > 0 ? ani_compute_full(ani, ntotal, nlocal, nullptr, coords, npairs, nullptr, nullptr, nullptr, /*ago=*/1,
-                                       eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, out_force,
+                                       eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, fout,
                                        eflag_atom ? out_eatom.data() : nullptr, out_virial)
                     : ANI_OK;
   } else if (use_fullnbr) {
     if (inum != nlocal) error->one(FLERR, "Pair ani: full neighbor list does not cover every local atom");
     rc = ani_compute_full(ani, ntotal, nlocal, species.data(), coords, npairs, flat_ilist.data(), flat_jlist.data(),
-                          flat_numneigh.data(), ago, eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, out_force,
+                          flat_numneigh.data(), ago, eflag_atom ? 1 : 0, vflag_either ? 1 : 0, &out_energy, fout,
                           eflag_atom ? out_eatom.data() : nullptr, out_virial);
   } else {
     rc = ani_compute_half(ani, ntotal, nlocal, species.data(), coords, npairs, atom_index12.data(), ago, eflag_atom ? 1 : 0,
-                          vflag_either ? 1 : 0, &out_energy, out_force, eflag_atom ? out_eatom.data() : nullptr, out_virial);
+                          vflag_either ? 1 : 0, &out_energy, fout, eflag_atom ? out_eatom.data() : nullptr, out_virial);
   }
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(ani));
 
@@ -330,10 +340,18 @@ void PairANI::compute(int eflag, int vflag) {
   // with newton off nobody reads the ghost rows of f (the reference adds them all the same and says so,
   // src/pair_ani.cpp:203-210); with newton on LAMMPS reverse-communicates f itself and needs them
   const int nadd = force->newton ? ntotal : nlocal;
-  for (int i = 0; i < nadd; i++) {
-    f[i][0] += out_force[3 * i + 0];
-    f[i][1] += out_force[3 * i + 1];
-    f[i][2] += out_force[3 * i + 2];
+  if (direct) {
+    // added by the library
+  } else if (nadd > 0 && f[nadd - 1] == f[0] + 3 * (size_t)(nadd - 1)) {
+    double* __restrict__ ff = &f[0][0];
+    const double* __restrict__ src = out_force;
+    for (size_t k = 0; k < 3 * (size_t)nadd; k++) ff[k] += src[k];
+  } else {
+    for (int i = 0; i < nadd; i++) {
+      f[i][0] += out_force[3 * i + 0];
+      f[i][1] += out_force[3 * i + 1];
+      f[i][2] += out_force[3 * i + 2];
+    }
   }
   if (eflag_global) eng_vdwl += out_energy;
   if (eflag_atom) {

@@ -73,6 +73,7 @@ class PairANI : public Pair {
   double* out_force = nullptr;
   size_t out_force_cap = 0;     // doubles
   bool out_force_pinned = false;
+  bool direct_add = false;      // the library adds into atom->f itself (option out_force_accumulate)
   void grow_out_force(size_t doubles);
   // the atom->x block of the current neighbour-list epoch, page-locked at ago == 0 and released at the next ago == 0 before
   // anything else is touched (LAMMPS reallocates atom arrays only while re-neighbouring); LAMMPS_ANI_NO_PIN=1 turns both off

@@ -466,3 +466,34 @@ def test_local_rank_maps_onto_the_visible_devices(model_cache, hip):
         ani.close()
     with pytest.raises(hip.AniError, match="cpu"):
         hip.ANI(p, -1)
+
+
+@pytest.mark.gpu
+def test_out_force_accumulate_adds_in_chunks_and_nothing_on_error(model_cache, hip, monkeypatch):
+    """Option out_force_accumulate: the host entry point ADDS the forces into the caller's array (three chunks here; one is the
+    default) and leaves it alone when the call fails."""
+    monkeypatch.setenv("ANI_FORCE_CHUNKS", "3")
+    sysm = hx.spatial_sort(hx.water_box(21000))
+    inp = hx.decompose(sysm)
+    ani = hip.ANI(model_cache("ani2x", 1, 11), 0)
+    ref = ani.compute(inp, ago=0)
+    assert inp.ntotal > 3 * 8192
+    rng = np.random.default_rng(0)
+    pre = rng.normal(size=(inp.ntotal, 3))
+    ani.set_option("out_force_accumulate", 1)
+    f = pre.copy()
+    out = ani.compute(inp, ago=1, force_into=f)
+    assert out["force"] is f
+    assert np.abs(f - (pre + ref["force"])).max() < 2e-5     # the force scatter's atomics are not ordered: last bits of fp32
+    assert abs(out["energy"] - ref["energy"]) < 1e-6
+    # a call that fails (capacity overflow with the retry exhausted is hard to stage: use the argument check) adds nothing
+    g = pre.copy()
+    with pytest.raises(hip.AniError):
+        bad = hx.RankInput(**{**inp.__dict__, "nlocal": inp.nlocal - 1, "nghost": inp.nghost + 1})   # not the list's split
+        ani.compute(bad, ago=1, force_into=g)
+    assert np.array_equal(g, pre)
+    ani.set_option("out_force_accumulate", 0)
+    h = pre.copy()
+    ani.compute(inp, ago=1, force_into=h)
+    assert np.abs(h - ref["force"]).max() < 2e-5             # overwritten, as ever
+    ani.close()
