@@ -39,6 +39,10 @@ int ani_comm_get_unique_id(void* id128);
 /* every rank, collectively (ncclCommInitRank); `device` = HIP device ordinal of this rank.  On failure *out is NULL and
  * ani_comm_last_error(NULL) holds the message. */
 int ani_comm_create(int nranks, int rank, const void* id128, int device, ani_comm** out);
+/* a communicator of ONE rank without RCCL (nothing is loaded, no id, not collective): every exchange is a device copy or one
+ * kernel.  For a caller whose run has a single rank -- all its ghosts are periodic images of its own atoms -- and that wants the
+ * ghost forces summed on the device (ani_attach_comm) without bringing RCCL up. */
+int ani_comm_create_local(int device, ani_comm** out);
 void ani_comm_destroy(ani_comm* c);
 const char* ani_comm_last_error(const ani_comm* c);
 int ani_comm_rank(const ani_comm* c);

@@ -149,7 +149,7 @@ int grow(ani_comm* c, T** p, size_t* cap, size_t n) {
 // one all-to-all of byte chunks: chunk p of `send` (offset so[p], sc[p] items) goes to rank p, chunk p of `recv` comes from it
 int a2a_bytes(ani_comm* c, const char* send, const int64_t* sc, const int64_t* so, char* recv, const int64_t* rc, const int64_t* ro,
               size_t item, hipStream_t st) {
-  Rccl* r = rccl();
+  Rccl* r = c->comm ? rccl() : nullptr;   // a local communicator (ani_comm_create_local) never gets as far as using it
   if (c->broken) { c->err = "the communicator is unusable after an earlier RCCL failure: " + c->err_first; return ANI_ERR_DEVICE; }
   c->n_a2a++;
   bool any = false;
@@ -230,6 +230,20 @@ int ani_comm_create(int nranks, int rank, const void* id128, int device, ani_com
   return ANI_OK;
 }
 
+int ani_comm_create_local(int device, ani_comm** out) {
+  if (out) *out = nullptr;
+  if (!out) { g_comm_create_error = "bad argument"; return ANI_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_comm_create_error = "no HIP device visible"; return ANI_ERR_DEVICE; }
+  ani_comm* c = new ani_comm;
+  c->nranks = 1; c->rank = 0; c->device = device % ndev;
+  if (hipSetDevice(c->device) != hipSuccess) { g_comm_create_error = "cannot select the HIP device"; delete c; return ANI_ERR_DEVICE; }
+  if (hipMalloc((void**)&c->d_counts, sizeof(int64_t) * 2) != hipSuccess) { g_comm_create_error = "hipMalloc failed"; delete c; return ANI_ERR_DEVICE; }
+  c->sc.assign(1, 0); c->rc.assign(1, 0); c->so.assign(1, 0); c->ro.assign(1, 0);
+  *out = c;   // c->comm stays NULL: every exchange of a one-rank communicator is a device copy or one kernel
+  return ANI_OK;
+}
+
 void ani_comm_destroy(ani_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -268,7 +282,11 @@ long long ani_comm_get_stat(const ani_comm* c, const char* name) {
 
 int ani_comm_set_option(ani_comm* c, const char* name, int value) {
   if (!c || !name) return ANI_ERR_ARG;
-  if (strcmp(name, "self_through_rccl") == 0) { c->self_rccl = value != 0; return ANI_OK; }
+  if (strcmp(name, "self_through_rccl") == 0) {
+    if (value && !c->comm) { c->err = "a local communicator (ani_comm_create_local) has no RCCL side"; return ANI_ERR_ARG; }
+    c->self_rccl = value != 0;
+    return ANI_OK;
+  }
   c->err = std::string("unknown option '") + name + "'";
   return ANI_ERR_ARG;
 }
@@ -425,6 +443,7 @@ int ani_comm_allreduce_f64(ani_comm* c, double* d_buf, int n, int op, void* stre
   if (!c || !d_buf || n < 0 || (op != 0 && op != 1)) return ANI_ERR_ARG;
   if (n == 0) return ANI_OK;
   if (c->broken) { c->err = "the communicator is unusable after an earlier RCCL failure: " + c->err_first; return ANI_ERR_DEVICE; }
+  if (!c->comm) return ANI_OK;   // a local communicator: one rank, the buffer is its own reduction
   COMM_HIP(c, hipSetDevice(c->device));
   COMM_NCCL(c, rccl()->AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->comm, (hipStream_t)stream));
   return ANI_OK;

@@ -131,6 +131,23 @@ void PairANI::create_model() {
     ani_attach_comm(ani, acomm);
     comm_forward = 2;
   }
+  // One rank (mpicomm or not): every ghost is a periodic image of an owned atom and comm->reverse_comm would only copy inside
+  // this process -- the library sums the image rows into their owners on the device instead, through a communicator that never
+  // loads RCCL, and 1.1 MB less comes back per step (100 002 atoms).  LAMMPS_ANI_NO_SELF_FOLD=1 keeps the host path.
+  use_self_fold = false;
+  if (!use_rccl) {
+    int nprocs = 1;
+    MPI_Comm_size(world, &nprocs);
+    const char* off = getenv("LAMMPS_ANI_NO_SELF_FOLD");
+    if (nprocs == 1 && !(off && off[0] && strcmp(off, "0") != 0)) {
+      if (acomm) { ani_comm_destroy(acomm); acomm = nullptr; }
+      if (ani_comm_create_local(node_local_rank(), &acomm) != ANI_OK)
+        error->one(FLERR, std::string("Pair ani: ") + ani_comm_last_error(nullptr));
+      ani_attach_comm(ani, acomm);
+      comm_forward = 2;
+      use_self_fold = true;
+    }
+  }
 }
 
 /* pair_style ani cutoff model_file device [num_models] [cuaev|pyaev] [full|half] [single|double] [hostlist|devlist]
@@ -289,12 +306,13 @@ void PairANI::compute(int eflag, int vflag) {
     }
   }
 
-  if (use_rccl && ago == 0) build_rccl_maps(nlocal, atom->nghost);
+  const bool dev_reverse = use_rccl || use_self_fold;   // the ghost rows go home on the device
+  if (dev_reverse && ago == 0) build_rccl_maps(nlocal, atom->nghost);
 
   // Where nothing reads the raw result before it is added to atom->f (rcclcomm: the ghost rows have gone home on the device;
   // newton on: LAMMPS reverse-communicates f itself) the library adds it into f directly, chunk by chunk beside its own copies
   // (option out_force_accumulate).  atom->f is one block in LAMMPS (memory->create); anything else keeps the buffer.
-  const bool direct = (use_rccl || force->newton) && ntotal > 0 && f[ntotal - 1] == f[0] + 3 * (size_t)(ntotal - 1);
+  const bool direct = (dev_reverse || force->newton) && ntotal > 0 && f[ntotal - 1] == f[0] + 3 * (size_t)(ntotal - 1);
   if (direct != direct_add) {
     ani_set_option(ani, "out_force_accumulate", direct ? 1 : 0);
     direct_add = direct;
@@ -331,7 +349,7 @@ void PairANI::compute(int eflag, int vflag) {
   if (rc != ANI_OK) error->one(FLERR, std::string("Pair ani: ") + ani_last_error(ani));
 
   // ghost forces go home from out_force (f's ghost entries are not cleared between steps when newton is off)
-  if (!force->newton && !use_rccl) {   // rcclcomm: the library has summed them on the device (ani_attach_comm)
+  if (!force->newton && !dev_reverse) {   // rcclcomm / one rank: the library has summed them on the device (ani_attach_comm)
     ani_trace_push("reverse_comm");   // src/pair_ani.cpp:198-200
     comm->reverse_comm(this);
     ani_trace_pop();

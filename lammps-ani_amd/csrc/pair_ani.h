@@ -57,6 +57,7 @@ class PairANI : public Pair {
   // `rcclcomm`: ghost forces go home on the device over RCCL (include/ani_comm.h) instead of through comm->reverse_comm(this)
   // on the host; not part of the restart record
   bool use_rccl = false;
+  bool use_self_fold = false;   // one rank: a local communicator (no RCCL) sums the image rows on the device
   ani_comm* acomm = nullptr;
   std::vector<double> owner_info;   // [ntotal][2] {owning rank, index on that rank}, filled for ghosts by forward_comm(this)
   void build_rccl_maps(int nlocal, int nghost);

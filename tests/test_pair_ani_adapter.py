@@ -170,7 +170,7 @@ def test_adapter_devlist_matches_hostlist(mock, model_cache, aev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("nbr", ["full", "half"])
-def test_adapter_rcclcomm_matches_mpicomm(mock, model_cache, nbr):
+def test_adapter_rcclcomm_matches_mpicomm(mock, model_cache, nbr, monkeypatch):
     """`... single hostlist rcclcomm`: the ghost-force reverse communication runs on the device through include/ani_comm.h
     (owners found with comm->forward_comm(this), maps handed to the library per re-neighbouring, forces summed before the
     D2H copy) instead of comm->reverse_comm(this) on the host (src/pair_ani.cpp:197-201,461-484).  One rank: the ghosts are
@@ -180,14 +180,24 @@ def test_adapter_rcclcomm_matches_mpicomm(mock, model_cache, nbr):
     inp = golden_input(g, half=(nbr == "half"))
     p = golden_model_path(g, model_cache)
     out = {}
-    for mode in ("mpicomm", "rcclcomm"):
+    # "mpicomm" on ONE rank sums the images on the device too (a communicator without RCCL); LAMMPS_ANI_NO_SELF_FOLD keeps
+    # comm->reverse_comm(this) on the host, the reference's path and the yardstick here
+    for mode in ("mpicomm host", "mpicomm", "rcclcomm"):
+        if mode == "mpicomm host":
+            monkeypatch.setenv("LAMMPS_ANI_NO_SELF_FOLD", "1")
+        else:
+            monkeypatch.delenv("LAMMPS_ANI_NO_SELF_FOLD", raising=False)
         h = mock.mock_create(b"real", 0)
-        rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", nbr, "single", "hostlist", mode])
+        rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", nbr, "single", "hostlist", mode.split()[0]])
         assert rc == 0, err
         for ago in (0, 1, 0):
             out[mode] = _run(mock, h, inp, ago)
         mock.mock_destroy(h)
-    (fm, em, vm, _), (fr, er, vr, _) = out["mpicomm"], out["rcclcomm"]
+    (fm, em, vm, _), (fr, er, vr, _) = out["mpicomm host"], out["rcclcomm"]
+    fs, es, vs, _ = out["mpicomm"]
+    np.testing.assert_allclose(fs[: inp.nlocal], fm[: inp.nlocal], rtol=0, atol=1e-3)
+    assert np.all(fs[inp.nlocal:] == 0.0) and abs(es - em) < 1e-6
+    np.testing.assert_allclose(vs, vm, rtol=0, atol=1e-2)
     np.testing.assert_allclose(fr[: inp.nlocal], fm[: inp.nlocal], rtol=0, atol=1e-3)
     assert np.all(fr[inp.nlocal:] == 0.0)
     assert abs(er - em) < 1e-6
