@@ -293,10 +293,11 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *             operands; the three dropped terms are below 2^-23 of the product: one fp32 rounding.
  *         0 = the fp32-input instruction v_mfma_f32_32x32x2_f32 (1/16 of the 16-bit matrix rate on gfx950).
  *   "mlp_split_bf16": earlier name; 1 selects "mlp_arith" 1, 0 selects "mlp_arith" 0.
- *   "mlp_pipeline" (default 1; per-layer kernels only): with one ensemble member, arithmetic 2, layers no wider than 256 and more 64-row
- *       tiles than one round of chained workgroups (about 32 000 water atoms) the six MLP products run as ONE launch of
- *       persistent workgroups that walk (layer, tile) items in order, each waiting for the flag of the same rows' item
- *       of the layer before; 2 = at any size (measurement knob), 0 = never.  Takes effect at the next call.
+ *   "mlp_pipeline" (default 0: an experiment; per-layer kernels only): 1 = with one ensemble member, arithmetic 2, layers no wider than
+ *       256 and more 64-row tiles than one round of chained workgroups (about 32 000 water atoms) the six MLP products run as ONE
+ *       launch of persistent workgroups that walk (layer, tile) items in order, each waiting for the flag of the same rows' item
+ *       of the layer before; 2 = at any size, 0 = never.  Not a default for anything since round 4: one run of the test suite in
+ *       three returned a stale tile at 60 000 atoms (a read across XCDs inside a launch).  Takes effect at the next call.
  *   "mlp_chain" (default 1; per-layer kernels only): with one ensemble member and few row tiles (small systems) the six MLP products run as one
  *       chained launch instead of six grouped ones; 2 = at any size (measurement knob), 0 = never.  Takes effect at the
  *       next call.

@@ -123,7 +123,9 @@ struct ani_handle {
   SpeciesMap cmap{};  // species -> index among the species present
   int active_mask = -1;
   bool prune = true;  // ani_set_option("prune_absent_species")
-  int mlp_pipeline = 1;   // ani_set_option("mlp_pipeline"): 1 = large systems run all MLP layers as one launch of persistent workgroups
+  int mlp_pipeline = 0;   // ani_set_option("mlp_pipeline"): 1 = large systems run all MLP layers as one launch of persistent workgroups
+                          // (two-term arithmetic, shapes off the fused kernel).  Off since round 4: one run of the test suite in
+                          // three returned a stale tile at 60 000 atoms (tests/test_hip_properties.py) -- an experiment, not a default
                           // with per-tile dependencies, 2 = at any size (measurement knob), 0 = one launch per layer
   int aev_fused = 1;         // ani_set_option("aev_fused"): 1 = neighbour compaction inside the forward AEV launch, 0 = its own kernel
   int aev_sym_radial = 1;        // ani_set_option("aev_symmetric_radial"): see AevArgs::row_of_atom
