@@ -209,3 +209,32 @@ def test_adapter_rcclcomm_matches_mpicomm(mock, model_cache, nbr, monkeypatch):
     h = mock.mock_create(b"real", 0)
     rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", nbr, "single", "hostlist", "ucxcomm"])
     assert rc == 1 and "mpicomm or rcclcomm" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["hostlist", "devlist"])
+def test_adapter_device_fold_and_direct_accumulation_at_a_size_that_takes_the_polled_copy(mock, model_cache, source, monkeypatch):
+    """6 000 water atoms (above the 4 096 rows from which the library brings the forces over by its copy-out kernel and adds them
+    into atom->f chunk by chunk): the one-rank default (device fold through a communicator without RCCL, direct accumulation)
+    against the host path (LAMMPS_ANI_NO_SELF_FOLD: full download, comm->reverse_comm, f += out_force), over a rebuild, two cached
+    steps and another rebuild.  f carries a non-zero start value in neither (the mock clears it, like LAMMPS' force_clear)."""
+    from lammps_ani_amd import harness as hx
+    inp = hx.decompose(hx.spatial_sort(hx.water_box(6000, seed=5)))
+    p = model_cache("ani2x", 2, 2024)
+    out = {}
+    for mode in ("host", "fold"):
+        if mode == "host":
+            monkeypatch.setenv("LAMMPS_ANI_NO_SELF_FOLD", "1")
+        else:
+            monkeypatch.delenv("LAMMPS_ANI_NO_SELF_FOLD", raising=False)
+        h = mock.mock_create(b"real", 0)
+        rc, err = _style(mock, h, ["5.1", p, "hip", "-1", "cuaev", "full", "single", source])
+        assert rc == 0, err
+        out[mode] = [_run(mock, h, inp, ago) for ago in (0, 1, 2, 0)]
+        mock.mock_destroy(h)
+    for (fh, eh, vh, eah), (ff, ef, vf, eaf) in zip(out["host"], out["fold"]):
+        np.testing.assert_allclose(ff[: inp.nlocal], fh[: inp.nlocal], rtol=0, atol=2e-4)
+        assert np.all(ff[inp.nlocal:] == 0.0)              # nothing left in the ghost rows: the images went home on the device
+        assert abs(ef - eh) < 1e-6 * max(1.0, abs(eh))
+        np.testing.assert_allclose(vf, vh, rtol=1e-6, atol=1e-2)
+        np.testing.assert_allclose(eaf, eah, rtol=0, atol=1e-6)
