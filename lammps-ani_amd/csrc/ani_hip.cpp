@@ -1289,7 +1289,8 @@ int finish_host(ani_handle* h, int ntotal, int nlocal, int eflag_atom, int vflag
                 double* out_atomic_energies, double* out_virial) {
   hipStream_t st = h->stream;
   if (!h->pinned_ev) {
-    HIP_TRY(h, hipHostMalloc((void**)&h->pinned_ev, sizeof(double) * 16, hipHostMallocDefault));
+    // written by kernels and read by a host that may be polling: fine-grained (coherent) whatever HIP_HOST_COHERENT says
+    HIP_TRY(h, hipHostMalloc((void**)&h->pinned_ev, sizeof(double) * 16, hipHostMallocCoherent));
     memset(h->pinned_ev, 0, sizeof(double) * 16);
   }
   const double* ev = h->pinned_ev;
@@ -1314,11 +1315,11 @@ int finish_host(ani_handle* h, int ntotal, int nlocal, int eflag_atom, int vflag
       if (h->stage_force) HIP_TRY(h, hipHostFree(h->stage_force));
       h->stage_force = nullptr;
       h->stage_force_cap = 3 * rows + 3 * rows / 2 + 64;
-      HIP_TRY(h, hipHostMalloc((void**)&h->stage_force, h->stage_force_cap * sizeof(double), hipHostMallocDefault));
+      HIP_TRY(h, hipHostMalloc((void**)&h->stage_force, h->stage_force_cap * sizeof(double), hipHostMallocCoherent));
     }
     if (polled) {
       if (!h->stage_flags) {
-        HIP_TRY(h, hipHostMalloc((void**)&h->stage_flags, sizeof(unsigned) * kChunks, hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc((void**)&h->stage_flags, sizeof(unsigned) * kChunks, hipHostMallocCoherent));
         memset(h->stage_flags, 0, sizeof(unsigned) * kChunks);
         HIP_TRY(h, h->copy_ctr.reserve(kChunks, true));
       }
