@@ -262,6 +262,10 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *     of a handle, counts and fills dense segments instead); ani_debug_list then returns row offsets i * capacity.  0 = separate
  *     search and grouping kernels.  "nbr_onepass" 0 = always count first, then fill.  "nbr_half_cells" (default 0): cells of half
  *     the cutoff, 5 x 5 x 5 of them searched.  The same neighbour sets in every case.
+ *   "mlp_fused_halves" (default 1; sixteen-row kernel): the static schedule of the fused launch may run an item as two HALF items (the
+ *     lower half of a workgroup's waves takes 64 of the 128 rows, the upper half only its share of the loads; ~0.7 of the item's
+ *     time each) where that shortens the launch -- the items beyond the last full round of workgroups otherwise make a round of
+ *     their own with most of the chip idle.  0 = whole items only, 2 = every item as two halves (tests, measurements).
  *   "reuse_build_list_upload" (default 0; the LAMMPS adapter turns it on): the ani_compute_full call that follows an
  *     ani_build_list with the SAME coordinates pointer uses the positions that call uploaded instead of uploading them again.
  *     For callers whose array has not changed in between (the same timestep); a caller that might hand over another array at a
@@ -333,6 +337,11 @@ int ani_debug_fused_stamps(unsigned long long* out16, int reset);
  * items_out[sum count] = item numbers, workgroup after workgroup; off_out[bins + 1]; *makespan_out = the largest workgroup load */
 int ani_debug_fused_schedule(int ntypes, const int* count, const double* cost, int bins, int* items_out, int* off_out,
                              double* makespan_out);
+/* the same with HALF items ("mlp_fused_halves"; the sixteen-row kernel runs item sum(count) + 2 i + h as half h of item i, at half_ratio
+ * of its cost): split_mode 0 none, 1 searched, 2 every item; split_out[ntypes] = how many of each type's LAST items were cut,
+ * items_out[2 sum(count)] (capacity), *n_items_out = entries written, *makespan_out = the bound the packing was made for */
+int ani_debug_fused_schedule_halves(int ntypes, const int* count, const double* cost, double half_ratio, int bins, int split_mode,
+                                    int* split_out, int* items_out, int* off_out, int* n_items_out, double* makespan_out);
 
 /* copy `bytes` from a device pointer of the view to host memory (synchronises the handle's stream first) */
 int ani_debug_read(ani_handle* h, const void* d_src, void* host_dst, uint64_t bytes);

@@ -22,7 +22,7 @@ EXPORTS = ["ani_create", "ani_destroy", "ani_last_error", "ani_num_models", "ani
            "ani_aev_length", "ani_cutoff_radial", "ani_cutoff_angular", "ani_compute_full", "ani_compute_half",
            "ani_compute_full_device", "ani_build_list_device", "ani_build_list", "ani_debug_list", "ani_debug_get", "ani_debug_read", "ani_debug_colmap", "ani_set_option", "ani_phase_timing", "ani_phase_times",
            "ani_trace_push", "ani_trace_pop", "ani_trace_mark", "ani_step_begin", "ani_step_ghosts_ready", "ani_step_finish",
-           "ani_debug_fused_stamps", "ani_attach_comm", "ani_debug_fused_schedule", "ani_last_mlp_kernel", "ani_host_register", "ani_host_unregister", "ani_set_ghost_fold", "ani_stage_ghost_fold"]
+           "ani_debug_fused_stamps", "ani_attach_comm", "ani_debug_fused_schedule", "ani_debug_fused_schedule_halves", "ani_last_mlp_kernel", "ani_host_register", "ani_host_unregister", "ani_set_ghost_fold", "ani_stage_ghost_fold"]
 # include/ani_comm.h: the device-side ghost exchange over RCCL
 COMM_EXPORTS = ["ani_comm_get_unique_id", "ani_comm_create", "ani_comm_create_local", "ani_comm_destroy", "ani_comm_last_error", "ani_comm_rank",
                 "ani_comm_size", "ani_comm_plan", "ani_comm_exchange_counts", "ani_comm_alltoallv", "ani_comm_set_epoch",

@@ -131,6 +131,9 @@ struct ani_handle {
   int aev_sym_radial = 1;        // ani_set_option("aev_symmetric_radial"): see AevArgs::row_of_atom
   int aev_tickets_min = 40000;   // ani_set_option("aev_tickets_min"): launches of fewer rows keep the fixed stride
   int mlp_fused_sched = 1;   // ani_set_option("mlp_fused_schedule"): 1 = static first-fit schedule of the fused launch, 0 = a counter
+  int mlp_fused_halves = 1;  // ani_set_option("mlp_fused_halves"): 1 = the schedule may cut straggler items in two (sixteen-row kernel),
+                             // 0 = whole items only, 2 = every item as two halves (tests, measurements)
+  int sched_nitems = 0;      // entries of the schedule in fused_sched (whole items + halves)
   const char* last_mlp_kernel = "";   // ani_last_mlp_kernel: the kernel that ran the MLP of the last step
   int mlp_fused = 1;   // ani_set_option("mlp_fused"): 1 = networks of three hidden layers run as one launch, a 128-row tile per
                        // workgroup with the activations in registers (ani_kernels_mlpf.hip); 0 = the per-layer kernels
@@ -462,6 +465,7 @@ int specialize(ani_handle* h, int mask) {
 
 // (re)build everything that depends on the neighbour list: offsets, species buckets, activation arena.
 // d_species/d_ilist/d_numneigh/d_jlist already hold this epoch's list in the handle's own buffers.
+constexpr double kFusedHalfCost = 0.75;   // cost of a half item of the sixteen-row fused MLP relative to its whole item (measured 0.64 - 0.76)
 constexpr int kCopyOutBlocks = 32;   // workgroups of launch_copy_out: enough stores in flight for the link, few enough to finish chunks in order
 constexpr int kRebuildRowsOverflow = -1000;   // internal: the rows of launch_nbr_sorted_rows were too short
 int rebuild(ani_handle* h, hipStream_t st) {
@@ -794,7 +798,7 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
     const int nitems = total * per_tile;
     int mix = np;   // the tile counts and shapes of the problems, folded into one word
     for (int q = 0; q < np; q++) mix = mix * 1000003 + G.p[q].tiles * 4 + G.p[q].shape;
-    mix = mix * 31 + sub + 2 * gen;
+    mix = mix * 31 + sub + 2 * gen + 4 * h->mlp_fused_halves;
     if (h->sched_key[0] != total || h->sched_key[1] != per_tile || h->sched_key[2] != mix || h->sched_key[3] != bins || !h->fused_sched.p) {
       // item types: one per problem; a (tile, member) item costs what its tile's member costs.  Item t of the kernel's numbering
       // is tile t / per_tile: the items of a problem are contiguous.
@@ -808,16 +812,22 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
                   12.0;   // MFMA blocks of a member + a little for what a tile costs whatever its size
         if (!G.member_items) cost[q] *= m.M;
       }
-      std::vector<int> items(std::max(nitems, 1)), off(bins + 1);
-      (void)fused_schedule(np, cnt, cost, bins, items.data(), off.data());
-      HIP_TRY(h, h->fused_sched.reserve((size_t)nitems + bins + 1));
-      HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p, items.data(), sizeof(int) * (size_t)nitems, hipMemcpyHostToDevice, st));
-      HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p + nitems, off.data(), sizeof(int) * (size_t)(bins + 1), hipMemcpyHostToDevice, st));
+      // the sixteen-row kernel takes half items: the schedule may cut the items of a last, mostly idle round in two.  A half costs
+      // kFusedHalfCost of its item (64 of 128 rows with all the weights streamed: measured, profiles/r04_mlp_halves.log)
+      std::vector<int> items((size_t)2 * std::max(nitems, 1)), off(bins + 1);
+      int nsched = nitems;
+      const int split_mode = !gen ? 0 : (h->mlp_fused_halves == 2 ? 2 : (sub != 2 ? h->mlp_fused_halves : 0));   // searched for 128-row tiles only
+      static const double half_cost = [] { const char* e = getenv("ANI_FUSED_HALF_COST"); return e ? atof(e) : kFusedHalfCost; }();
+      (void)fused_schedule_halves(np, cnt, cost, half_cost, bins, split_mode, nullptr, items.data(), off.data(), &nsched);
+      HIP_TRY(h, h->fused_sched.reserve((size_t)nsched + bins + 1));
+      HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p, items.data(), sizeof(int) * (size_t)nsched, hipMemcpyHostToDevice, st));
+      HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p + nsched, off.data(), sizeof(int) * (size_t)(bins + 1), hipMemcpyHostToDevice, st));
       HIP_TRY(h, hipStreamSynchronize(st));   // items / off are locals; once per re-neighbouring
+      h->sched_nitems = nsched;
       h->sched_key[0] = total; h->sched_key[1] = per_tile; h->sched_key[2] = mix; h->sched_key[3] = bins;
     }
     G.sched_items = h->fused_sched.p;
-    G.sched_off = h->fused_sched.p + nitems;
+    G.sched_off = h->fused_sched.p + h->sched_nitems;
     G.sched_blocks = bins;
   }
   if (gen) {
@@ -2003,6 +2013,12 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
     h->sched_key[0] = -1;
     return ANI_OK;
   }
+  if (strcmp(name, "mlp_fused_halves") == 0) {
+    if (value < 0 || value > 2) { h->err = "mlp_fused_halves must be 0, 1 or 2"; return ANI_ERR_ARG; }
+    h->mlp_fused_halves = value;
+    h->sched_key[0] = -1;
+    return ANI_OK;
+  }
   if (strcmp(name, "mlp_fused_schedule") == 0) {
     h->mlp_fused_sched = value != 0;
     h->sched_key[0] = -1;
@@ -2042,6 +2058,18 @@ int ani_set_option(ani_handle* h, const char* name, int value) {
 int ani_debug_fused_stamps(unsigned long long* out32, int reset) {   // 1: fused MLP stamps, 2: AEV backward stamps, 0: neither built in
   const int r = fused_read_stamps(out32, reset);
   return r ? r : aev_read_stamps(out32, reset);
+}
+
+int ani_debug_fused_schedule_halves(int ntypes, const int* count, const double* cost, double half_ratio, int bins, int split_mode,
+                                    int* split_out, int* items_out, int* off_out, int* n_items_out, double* makespan_out) {
+  if (ntypes < 1 || ntypes > kMaxProblems || !count || !cost || bins < 1 || !items_out || !off_out || split_mode < 0 || split_mode > 2 ||
+      !(half_ratio > 0.0))
+    return ANI_ERR_ARG;
+  for (int j = 0; j < ntypes; j++)
+    if (count[j] < 0 || !(cost[j] > 0.0)) return ANI_ERR_ARG;
+  const double T = fused_schedule_halves(ntypes, count, cost, half_ratio, bins, split_mode, split_out, items_out, off_out, n_items_out);
+  if (makespan_out) *makespan_out = T;
+  return ANI_OK;
 }
 
 int ani_debug_fused_schedule(int ntypes, const int* count, const double* cost, int bins, int* items_out, int* off_out,

@@ -150,6 +150,9 @@ int fused_num_cus();
 // (Drawing items from a counter, costliest first, is list scheduling: at 100 002 water atoms -- 521 + 261 tiles of cost 1 and
 // 0.67 on 256 CUs -- its last 14 tiles start when most CUs have finished, makespan 3.35; first-fit finds 3.0.)
 double fused_schedule(int nitem_types, const int* count, const double* cost, int bins, int* items_out, int* off_out);
+// the same with half items for the sixteen-row kernel (ids total + 2 i + h); see ani_kernels_mlpf.hip
+double fused_schedule_halves(int nitem_types, const int* count, const double* cost, double half_ratio, int bins, int split_mode,
+                             int* split_out, int* items_out, int* off_out, int* n_items_out);
 // dst[i] = sum over m < M of parts[m * part_stride + i], i < n (n a multiple of 4, 16-byte aligned pointers)
 void launch_sum_parts(const float* parts, long long part_stride, int M, float* dst, long long n, hipStream_t st);
 // diagnostic builds (-DABLF_STAMPS) only: cycles per phase summed over tiles; returns 0 in the shipped build

@@ -799,13 +799,15 @@ int fused_num_cus() {
   return ncu;
 }
 
-double fused_schedule(int ntypes, const int* count, const double* cost, int bins, int* items_out, int* off_out) {
-  std::vector<int> order(ntypes), first(ntypes + 1, 0);
-  for (int j = 0; j < ntypes; j++) { order[j] = j; first[j + 1] = first[j] + count[j]; }
+namespace {
+// multifit: the smallest makespan T for which first-fit-decreasing packs every item; take[b * ntypes + j] = items of type j in bin b
+double fused_pack(int ntypes, const int* count, const double* cost, int bins, std::vector<int>& best) {
+  std::vector<int> order(ntypes);
+  for (int j = 0; j < ntypes; j++) order[j] = j;
   std::sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
   double total = 0.0, cmax = 0.0;
   for (int j = 0; j < ntypes; j++) { total += count[j] * cost[j]; if (count[j] > 0) cmax = std::max(cmax, cost[j]); }
-  std::vector<int> take((size_t)bins * ntypes), best;
+  std::vector<int> take((size_t)bins * ntypes);
   auto fits = [&](double T) {
     std::fill(take.begin(), take.end(), 0);
     std::vector<double> rem(bins, T);
@@ -828,6 +830,15 @@ double fused_schedule(int ntypes, const int* count, const double* cost, int bins
     const double mid = 0.5 * (lo + hi);
     if (fits(mid)) { hi = mid; best = take; } else lo = mid;
   }
+  return hi;
+}
+}  // namespace
+
+double fused_schedule(int ntypes, const int* count, const double* cost, int bins, int* items_out, int* off_out) {
+  std::vector<int> best, first(ntypes + 1, 0), order(ntypes);
+  for (int j = 0; j < ntypes; j++) { order[j] = j; first[j + 1] = first[j] + count[j]; }
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  const double T = fused_pack(ntypes, count, cost, bins, best);
   std::vector<int> next(first.begin(), first.end() - 1);
   int n = 0;
   for (int b = 0; b < bins; b++) {
@@ -838,7 +849,80 @@ double fused_schedule(int ntypes, const int* count, const double* cost, int bins
     }
   }
   off_out[bins] = n;
-  return hi;
+  return T;
+}
+
+// The same with HALF items (the sixteen-row kernel: item total + 2 i + h = half h of item i, run by the lower half of a
+// workgroup's waves at half_ratio of the item's cost -- more than half: the weights stream through the workgroup all the same).
+// The last split[j] items of type j are cut in two where that shortens the schedule: the items beyond the last full round of
+// workgroups otherwise make a round of their own with most of the chip idle.  split_mode 1: searched (a few candidate counts per
+// type, most expensive types first, two sweeps; kept only if the makespan falls by 8 % -- the cost model is good to about 5 %:
+// 10 002 atoms x 8 members, predicted 7 % shorter, measured 2.5 % longer), 2: every item (tests, measurements).
+// items_out holds up to sum(count) + max splits entries.  Returns the makespan; *n_items_out = entries written.
+double fused_schedule_halves(int ntypes, const int* count, const double* cost, double half_ratio, int bins, int split_mode, int* split_out,
+                             int* items_out, int* off_out, int* n_items_out) {
+  std::vector<int> first(ntypes + 1, 0);
+  for (int j = 0; j < ntypes; j++) first[j + 1] = first[j] + count[j];
+  const int total = first[ntypes];
+  std::vector<int> split(ntypes, 0), ecount(2 * ntypes), best;
+  std::vector<double> ecost(2 * ntypes);
+  for (int j = 0; j < ntypes; j++) { ecost[j] = cost[j]; ecost[ntypes + j] = half_ratio * cost[j]; }
+  auto makespan = [&](const std::vector<int>& sp, std::vector<int>& take) {
+    for (int j = 0; j < ntypes; j++) { ecount[j] = count[j] - sp[j]; ecount[ntypes + j] = 2 * sp[j]; }
+    return fused_pack(2 * ntypes, ecount.data(), ecost.data(), bins, take);
+  };
+  double T = makespan(split, best);
+  if (split_mode == 2) {
+    for (int j = 0; j < ntypes; j++) split[j] = count[j];
+    T = makespan(split, best);
+  } else if (split_mode == 1) {
+    const double T0 = T;
+    std::vector<int> order(ntypes), cur = split, take;
+    for (int j = 0; j < ntypes; j++) order[j] = j;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] * count[a] > cost[b] * count[b]; });
+    double Tc = T;
+    for (int sweep = 0; sweep < 2; sweep++)
+      for (int jj = 0; jj < ntypes && jj < 4; jj++) {
+        const int j = order[jj];
+        if (count[j] == 0) continue;
+        const int cap = std::min(count[j], bins);
+        const int cand[7] = {0, count[j] % bins, cap / 8, cap / 4, cap / 2, (3 * cap) / 4, cap};
+        int keep = cur[j];
+        for (int c : cand) {
+          if (c < 0 || c > count[j]) continue;
+          std::vector<int> trial = cur;
+          trial[j] = c;
+          const double Tt = makespan(trial, take);
+          if (Tt < Tc * (1.0 - 1e-6)) { Tc = Tt; keep = c; }
+        }
+        cur[j] = keep;
+      }
+    if (Tc < 0.92 * T0) { split = cur; T = makespan(split, best); }
+    else T = makespan(split, best);
+  }
+  // numbering: type j's whole items first[j] .. first[j] + count[j] - split[j]; the halves of the split[j] items behind them
+  std::vector<int> order(2 * ntypes), next(2 * ntypes, 0);
+  for (int j = 0; j < 2 * ntypes; j++) order[j] = j;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return ecost[a] > ecost[b]; });
+  int n = 0;
+  for (int b = 0; b < bins; b++) {
+    off_out[b] = n;
+    for (int jj = 0; jj < 2 * ntypes; jj++) {
+      const int e = order[jj];
+      for (int k = 0; k < best[(size_t)b * 2 * ntypes + e]; k++) {
+        const int i = next[e]++;
+        if (e < ntypes) items_out[n++] = first[e] + i;
+        else {
+          const int j = e - ntypes;
+          items_out[n++] = total + 2 * (first[j] + count[j] - split[j] + (i >> 1)) + (i & 1);
+        }
+      }
+    }
+  }
+  off_out[bins] = n;
+  if (split_out) for (int j = 0; j < ntypes; j++) split_out[j] = split[j];
+  if (n_items_out) *n_items_out = n;
+  return T;
 }
 
 hipError_t launch_mlp_fused(const FusedArgs& G, MlpArith arith, hipStream_t st) {

@@ -223,17 +223,23 @@ constexpr int kPF = ANI_G_PF;
 
 // acc[NT] += W (stream) * X, X in registers: KS k-steps, a slab per k-step.  n_after: size of the slab that follows this
 // product's last one in the stream.
-template <int KS, int NT, int NTX, int P, int W>
+// ACT = false: the wave has no rows in this work item (the upper waves of a half item): it keeps its share of the loads and every
+// rendezvous -- the calls of g_boundary / g_drip / g_flush are the same statements, in the same order -- and does nothing else.
+template <int KS, int NT, int NTX, int P, int W, bool ACT = true>
 __device__ __forceinline__ void g_product_fwd(RingG& r, const f32x4g (&X)[NTX], f32x4g (&acc)[NT], float a_scale, int n_after, int wave,
                                               unsigned lane16) {
   static_assert(NTX == 2 * KS && NT >= 4 && NT * P <= kGSlot && NT > kPF, "shape");
   constexpr int N = NT * P, NB = KS * NT;
   FragG<P> bq[2], fa[kPF + 1];
+  if constexpr (ACT) {
 #pragma unroll
-  for (int i = 0; i < 4; i++) g_split_of<P>(X, 0, i, a_scale, bq[0]);
+    for (int i = 0; i < 4; i++) g_split_of<P>(X, 0, i, a_scale, bq[0]);
+  }
   const unsigned char* base = g_boundary<W>(r, KS > 1 ? N : n_after, wave, lane16);
+  if constexpr (ACT) {
 #pragma unroll
-  for (int q = 0; q < kPF; q++) g_read<P>(base, q, fa[q]);
+    for (int q = 0; q < kPF; q++) g_read<P>(base, q, fa[q]);
+  }
 #pragma unroll
   for (int ks = 0; ks < KS; ks++) {
 #pragma unroll
@@ -242,12 +248,16 @@ __device__ __forceinline__ void g_product_fwd(RingG& r, const f32x4g (&X)[NTX], 
       if (nx < NB) {
         const int nks = nx / NT, nnt = nx % NT;
         if (nnt == 0) base = g_boundary<W>(r, nks + 1 < KS ? N : n_after, wave, lane16);   // slab nks starts: slab nks + 1 is asked for
-        g_read<P>(base, nnt, fa[nx % (kPF + 1)]);
+        if constexpr (ACT) g_read<P>(base, nnt, fa[nx % (kPF + 1)]);
       }
-      if (ks + 1 < KS && nt < 4) g_split_of<P>(X, ks + 1, nt, a_scale, bq[(ks + 1) & 1]);
+      if constexpr (ACT) {
+        if (ks + 1 < KS && nt < 4) g_split_of<P>(X, ks + 1, nt, a_scale, bq[(ks + 1) & 1]);
+      }
       g_drip<W>(r, lane16);
-      g_mma<P>(fa[idx % (kPF + 1)], bq[ks & 1], acc[nt]);
-      if (nt == 3 && ks + 1 < KS) g_pin<P>(bq[(ks + 1) & 1]);
+      if constexpr (ACT) {
+        g_mma<P>(fa[idx % (kPF + 1)], bq[ks & 1], acc[nt]);
+        if (nt == 3 && ks + 1 < KS) g_pin<P>(bq[(ks + 1) & 1]);
+      }
     }
   }
 }
@@ -264,21 +274,25 @@ __host__ __device__ constexpr int g_inplace_slab_pieces(int s) {   // pieces of 
   if (first >= NT) return 0;
   return ((NT - first < tps) ? NT - first : tps) * KS * P;
 }
-template <int KS, int NT, int NTX, int P, int W>
+template <int KS, int NT, int NTX, int P, int W, bool ACT = true>
 __device__ __forceinline__ void g_product_inplace(RingG& r, const f32x4g (&X)[NTX], f32x4g (&Y)[NT], float a_scale, float inv,
                                                   float inv_alpha, int n_after, int wave, unsigned lane16) {
   static_assert(NTX == 2 * KS && KS * P <= kGSlot && KS > kPF, "shape");
   constexpr int TPS = GInplace<KS, P>::tps, NB = NT * KS;
   FragG<P> bf[KS], fa[kPF + 1];
+  if constexpr (ACT) {
 #pragma unroll
-  for (int i = 0; i < 4; i++) g_split_of<P>(X, 0, i, a_scale, bf[0]);
+    for (int i = 0; i < 4; i++) g_split_of<P>(X, 0, i, a_scale, bf[0]);
+  }
   f32x4g acc[2];
   const unsigned char* base = g_boundary<W>(r, g_inplace_slab_pieces<KS, NT, P>(1) > 0 ? g_inplace_slab_pieces<KS, NT, P>(1) : n_after, wave, lane16);
+  if constexpr (ACT) {
 #pragma unroll
-  for (int q = 0; q < kPF; q++) g_read<P>(base, q, fa[q]);
+    for (int q = 0; q < kPF; q++) g_read<P>(base, q, fa[q]);
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) {
-    acc[nt & 1] = f32x4g{0.f, 0.f, 0.f, 0.f};
+    if constexpr (ACT) acc[nt & 1] = f32x4g{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
       const int idx = nt * KS + ks, nx = idx + kPF;
@@ -288,23 +302,29 @@ __device__ __forceinline__ void g_product_inplace(RingG& r, const f32x4g (&X)[NT
           const int n2 = g_inplace_slab_pieces<KS, NT, P>(s + 1);
           base = g_boundary<W>(r, n2 > 0 ? n2 : n_after, wave, lane16);
         }
-        g_read<P>(base, lb, fa[nx % (kPF + 1)]);
+        if constexpr (ACT) g_read<P>(base, lb, fa[nx % (kPF + 1)]);
       }
-      if (nt == 0 && ks + 1 < KS) {
+      if constexpr (ACT) {
+        if (nt == 0 && ks + 1 < KS) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) g_split_of<P>(X, ks + 1, i, a_scale, bf[ks + 1]);
+          for (int i = 0; i < 4; i++) g_split_of<P>(X, ks + 1, i, a_scale, bf[ks + 1]);
+        }
       }
       g_drip<W>(r, lane16);
-      g_mma<P>(fa[idx % (kPF + 1)], bf[ks], acc[nt & 1]);
-      if (nt == 0 && ks + 1 < KS) g_pin<P>(bf[ks + 1]);
-      if (ks == (KS > 1 ? 1 : 0) && nt > 0) {
+      if constexpr (ACT) {
+        g_mma<P>(fa[idx % (kPF + 1)], bf[ks], acc[nt & 1]);
+        if (nt == 0 && ks + 1 < KS) g_pin<P>(bf[ks + 1]);
+        if (ks == (KS > 1 ? 1 : 0) && nt > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) Y[nt - 1][i] = acc[(nt - 1) & 1][i] * inv * dcelu_from_h(Y[nt - 1][i], inv_alpha);
+          for (int i = 0; i < 4; i++) Y[nt - 1][i] = acc[(nt - 1) & 1][i] * inv * dcelu_from_h(Y[nt - 1][i], inv_alpha);
+        }
       }
     }
   }
+  if constexpr (ACT) {
 #pragma unroll
-  for (int i = 0; i < 4; i++) Y[NT - 1][i] = acc[(NT - 1) & 1][i] * inv * dcelu_from_h(Y[NT - 1][i], inv_alpha);
+    for (int i = 0; i < 4; i++) Y[NT - 1][i] = acc[(NT - 1) & 1][i] * inv * dcelu_from_h(Y[NT - 1][i], inv_alpha);
+  }
 }
 
 // constants of a member in LDS (floats): b0[16 NT1] b1[16 NT2] b2[16 NT3] w3[16 NT3] then {b3, inv[6]} -- the layout of the
@@ -344,17 +364,21 @@ __host__ __device__ inline int g_b1_chunk_tiles(int nt0, int ci) {
 }
 
 // one chunk of NTC (compile-time) dE/dAEV tiles: all k-steps of g1, a slab per k-step
-template <int NTC, int KS, int NT1, int P, int W>
+template <int NTC, int KS, int NT1, int P, int W, bool ACT = true>
 __device__ __forceinline__ void g_b1_chunk(RingG& r, const f32x4g (&G1)[NT1], f32x4g (&acc)[NTC], float a_scale, int n_after, int wave,
                                            unsigned lane16) {
   static_assert(NT1 == 2 * KS && NTC >= 4 && NTC > kPF, "shape");
   constexpr int N = NTC * P, NB = KS * NTC;
   FragG<P> bq[2], fa[kPF + 1];
+  if constexpr (ACT) {
 #pragma unroll
-  for (int i = 0; i < 4; i++) g_split_of<P>(G1, 0, i, a_scale, bq[0]);
+    for (int i = 0; i < 4; i++) g_split_of<P>(G1, 0, i, a_scale, bq[0]);
+  }
   const unsigned char* base = g_boundary<W>(r, KS > 1 ? N : n_after, wave, lane16);
+  if constexpr (ACT) {
 #pragma unroll
-  for (int q = 0; q < kPF; q++) g_read<P>(base, q, fa[q]);
+    for (int q = 0; q < kPF; q++) g_read<P>(base, q, fa[q]);
+  }
 #pragma unroll
   for (int ks = 0; ks < KS; ks++) {
 #pragma unroll
@@ -363,30 +387,38 @@ __device__ __forceinline__ void g_b1_chunk(RingG& r, const f32x4g (&G1)[NT1], f3
       if (nx < NB) {
         const int nks = nx / NTC, nt = nx % NTC;
         if (nt == 0) base = g_boundary<W>(r, nks + 1 < KS ? N : n_after, wave, lane16);
-        g_read<P>(base, nt, fa[nx % (kPF + 1)]);
+        if constexpr (ACT) g_read<P>(base, nt, fa[nx % (kPF + 1)]);
       }
-      if (ks + 1 < KS && t < 4) g_split_of<P>(G1, ks + 1, t, a_scale, bq[(ks + 1) & 1]);
+      if constexpr (ACT) {
+        if (ks + 1 < KS && t < 4) g_split_of<P>(G1, ks + 1, t, a_scale, bq[(ks + 1) & 1]);
+      }
       g_drip<W>(r, lane16);
-      g_mma<P>(fa[idx % (kPF + 1)], bq[ks & 1], acc[t]);
-      if (t == 3 && ks + 1 < KS) g_pin<P>(bq[(ks + 1) & 1]);
+      if constexpr (ACT) {
+        g_mma<P>(fa[idx % (kPF + 1)], bq[ks & 1], acc[t]);
+        if (t == 3 && ks + 1 < KS) g_pin<P>(bq[(ks + 1) & 1]);
+      }
     }
   }
 }
 // the last, narrower chunk (ntc < 8 tiles, run-time): plain loops, a boundary in front of every slab
-template <int KS, int NT1, int P, int W>
+template <int KS, int NT1, int P, int W, bool ACT = true>
 __device__ __forceinline__ void g_b1_tail(RingG& r, const f32x4g (&G1)[NT1], f32x4g (&acc)[8], int ntc, float a_scale, int n_after, int wave,
                                           unsigned lane16) {
   FragG<P> bq, fa;
 #pragma unroll
   for (int ks = 0; ks < KS; ks++) {
+    if constexpr (ACT) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) g_split_of<P>(G1, ks, i, a_scale, bq);
+      for (int i = 0; i < 4; i++) g_split_of<P>(G1, ks, i, a_scale, bq);
+    }
     const unsigned char* base = g_boundary<W>(r, ks + 1 < KS ? ntc * P : n_after, wave, lane16);
+    if constexpr (ACT) {
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-      if (t < ntc) {
-        g_read<P>(base, t, fa);
-        g_mma<P>(fa, bq, acc[t]);
+      for (int t = 0; t < 8; t++) {
+        if (t < ntc) {
+          g_read<P>(base, t, fa);
+          g_mma<P>(fa, bq, acc[t]);
+        }
       }
     }
     g_flush<W>(r, lane16);
@@ -406,9 +438,11 @@ __device__ __forceinline__ void g_store_chunk(const f32x4g (&acc)[NTC], int ntc,
   }
 }
 
-// One (16 W)-row tile of a species bucket.  Shape (NT1, NT2, NT3): 16-feature tiles of the three hidden layers.
-template <int NT1, int NT2, int NT3, int P, int W>
-__device__ __forceinline__ void g_tile(const GTileCtx& cx, const FusedProb& pr, int tile, int wave, int lane, unsigned char* ring, float* cst) {
+// One work item of a species bucket: the 16-row strips from row0 on, one per ACTIVE wave (a whole tile: all W waves and
+// row0 = tile * 16 W; a half item: the lower W / 2 waves, the others run with ACT = false).  Shape (NT1, NT2, NT3): 16-feature
+// tiles of the three hidden layers.
+template <int NT1, int NT2, int NT3, int P, int W, bool ACT>
+__device__ __forceinline__ void g_tile(const GTileCtx& cx, const FusedProb& pr, int row0, int wave, int lane, unsigned char* ring, float* cst) {
   using CL = GConst<NT1, NT2, NT3>;
   static_assert(CL::count * 4 <= kGConstBytes, "constants do not fit their LDS block");
   static_assert(NT1 % 2 == 0 && NT2 % 2 == 0 && NT3 % 2 == 0, "whole k-steps");
@@ -417,11 +451,16 @@ __device__ __forceinline__ void g_tile(const GTileCtx& cx, const FusedProb& pr, 
   static_assert(N_F1 <= kGSlot && 16 * P <= kGSlot, "every slab must fit a slot");
   const int c = lane & 15, g = lane >> 4;
   const unsigned lane16 = lane * 16;
-  const int row = tile * (16 * W) + 16 * wave + c;
-  const float valid = pr.centre_of_row[row] >= 0 ? cx.scale : 0.f;
-  const float* __restrict__ arow = pr.aev + (size_t)row * pr.aev_stride + 8 * g;
-  float* __restrict__ grow = (cx.parts ? cx.parts + (size_t)cx.m0 * cx.part_stride + (size_t)pr.gaev_row0 * pr.aev_stride : pr.gaev) +
-                             (size_t)row * pr.aev_stride + 4 * g;
+  const int row = ACT ? row0 + 16 * wave + c : 0;
+  float valid = 0.f;
+  const float* __restrict__ arow = nullptr;
+  float* __restrict__ grow = nullptr;
+  if constexpr (ACT) {
+    valid = pr.centre_of_row[row] >= 0 ? cx.scale : 0.f;
+    arow = pr.aev + (size_t)row * pr.aev_stride + 8 * g;
+    grow = (cx.parts ? cx.parts + (size_t)cx.m0 * cx.part_stride + (size_t)pr.gaev_row0 * pr.aev_stride : pr.gaev) +
+           (size_t)row * pr.aev_stride + 4 * g;
+  }
   const int acols = pr.acols, ks1 = (acols + 31) >> 5, nt0 = (acols + 15) >> 4;
   const int nchunks = g_b1_chunks(nt0);
   RingG r;
@@ -439,66 +478,78 @@ __device__ __forceinline__ void g_tile(const GTileCtx& cx, const FusedProb& pr, 
       g_flush<W>(r, lane16);
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    const float inv_f1 = cst[CL::tail + 1], inv_f2 = cst[CL::tail + 2], inv_f3 = cst[CL::tail + 3];
-    const float inv_b3 = cst[CL::tail + 4], inv_b2 = cst[CL::tail + 5], inv_b1 = cst[CL::tail + 6];
-    const float b3 = cst[CL::tail];
+    float inv_f1 = 0.f, inv_f2 = 0.f, inv_f3 = 0.f, inv_b3 = 0.f, inv_b2 = 0.f, inv_b1 = 0.f, b3 = 0.f;
+    if constexpr (ACT) {
+      inv_f1 = cst[CL::tail + 1]; inv_f2 = cst[CL::tail + 2]; inv_f3 = cst[CL::tail + 3];
+      inv_b3 = cst[CL::tail + 4]; inv_b2 = cst[CL::tail + 5]; inv_b1 = cst[CL::tail + 6];
+      b3 = cst[CL::tail];
+    }
 
     // ---- F1: h1 = celu(W0 aev + b0); B operand from the AEV rows, a k-step = 32 columns = 8 per lane, requested two k-steps ahead
     f32x4g X1[NT1];
-    g_zero(X1);
+    if constexpr (ACT) g_zero(X1);
     {
       const float4 z4 = make_float4(0, 0, 0, 0);
       auto ld = [&](int ks, float4& a, float4& b) {
         a = z4; b = z4;
-        if (ks < ks1 && 32 * ks + 8 * g < acols) {
-          a = *reinterpret_cast<const float4*>(arow + 32 * ks);
-          b = *reinterpret_cast<const float4*>(arow + 32 * ks + 4);
+        if constexpr (ACT) {
+          if (ks < ks1 && 32 * ks + 8 * g < acols) {
+            a = *reinterpret_cast<const float4*>(arow + 32 * ks);
+            b = *reinterpret_cast<const float4*>(arow + 32 * ks + 4);
+          }
         }
       };
       auto cvt = [&](int i, const float4& a, const float4& b, FragG<P>& f) {
-        if (i == 0) g_split_pair<P>(a.x, a.y, cx.a_fwd, 0, f);
-        if (i == 1) g_split_pair<P>(a.z, a.w, cx.a_fwd, 1, f);
-        if (i == 2) g_split_pair<P>(b.x, b.y, cx.a_fwd, 2, f);
-        if (i == 3) g_split_pair<P>(b.z, b.w, cx.a_fwd, 3, f);
+        if constexpr (ACT) {
+          if (i == 0) g_split_pair<P>(a.x, a.y, cx.a_fwd, 0, f);
+          if (i == 1) g_split_pair<P>(a.z, a.w, cx.a_fwd, 1, f);
+          if (i == 2) g_split_pair<P>(b.x, b.y, cx.a_fwd, 2, f);
+          if (i == 3) g_split_pair<P>(b.z, b.w, cx.a_fwd, 3, f);
+        }
       };
       float4 c0a, c0b, v1a, v1b, v2a, v2b, w2a, w2b;
       ld(0, c0a, c0b); ld(1, v1a, v1b); ld(2, v2a, v2b);
       FragG<P> b0, b1, fa[2];
 #pragma unroll
       for (int i = 0; i < 4; i++) cvt(i, c0a, c0b, b0);
-      b1 = b0;
+      if constexpr (ACT) b1 = b0;
       const unsigned char* base = g_boundary<W>(r, ks1 > 1 ? N_F1 : N_F2, wave, lane16);
-      g_read<P>(base, 0, fa[0]);
+      if constexpr (ACT) g_read<P>(base, 0, fa[0]);
       for (int ks = 0; ks < ks1; ks++) {
         ld(ks + 3, w2a, w2b);
 #pragma unroll
         for (int nt = 0; nt < NT1; nt++) {
-          if (nt + 1 < NT1) g_read<P>(base, nt + 1, fa[(nt + 1) & 1]);
-          else if (ks + 1 < ks1) {
+          if (nt + 1 < NT1) {
+            if constexpr (ACT) g_read<P>(base, nt + 1, fa[(nt + 1) & 1]);
+          } else if (ks + 1 < ks1) {
             base = g_boundary<W>(r, ks + 2 < ks1 ? N_F1 : N_F2, wave, lane16);
-            g_read<P>(base, 0, fa[0]);     // NT1 is even: block 0 of every slab lands in fragment set 0
+            if constexpr (ACT) g_read<P>(base, 0, fa[0]);     // NT1 is even: block 0 of every slab lands in fragment set 0
           }
           if (nt < 4) cvt(nt, v1a, v1b, b1);   // k-step ks + 1
           g_drip<W>(r, lane16);
-          g_mma<P>(fa[nt & 1], b0, X1[nt]);
-          if (nt == 3) g_pin<P>(b1);
+          if constexpr (ACT) {
+            g_mma<P>(fa[nt & 1], b0, X1[nt]);
+            if (nt == 3) g_pin<P>(b1);
+          }
         }
-        b0 = b1;
-        v1a = v2a; v1b = v2b; v2a = w2a; v2b = w2b;
+        if constexpr (ACT) {
+          b0 = b1;
+          v1a = v2a; v1b = v2b; v2a = w2a; v2b = w2b;
+        }
       }
     }
-    g_epilogue_celu(X1, cst + CL::b0, g, inv_f1, cx.alpha, cx.inv_alpha);
+    if constexpr (ACT) g_epilogue_celu(X1, cst + CL::b0, g, inv_f1, cx.alpha, cx.inv_alpha);
 
     // ---- F2, F3 ----
     f32x4g X2[NT2];
-    g_zero(X2);
-    g_product_fwd<NT1 / 2, NT2, NT1, P, W>(r, X1, X2, cx.a_fwd, N_F3, wave, lane16);
-    g_epilogue_celu(X2, cst + CL::b1, g, inv_f2, cx.alpha, cx.inv_alpha);
+    if constexpr (ACT) g_zero(X2);
+    g_product_fwd<NT1 / 2, NT2, NT1, P, W, ACT>(r, X1, X2, cx.a_fwd, N_F3, wave, lane16);
+    if constexpr (ACT) g_epilogue_celu(X2, cst + CL::b1, g, inv_f2, cx.alpha, cx.inv_alpha);
     f32x4g X3[NT3];
-    g_zero(X3);
-    g_product_fwd<NT2 / 2, NT3, NT2, P, W>(r, X2, X3, cx.a_fwd, N_B3, wave, lane16);
+    if constexpr (ACT) g_zero(X3);
+    g_product_fwd<NT2 / 2, NT3, NT2, P, W, ACT>(r, X2, X3, cx.a_fwd, N_B3, wave, lane16);
     // last hidden layer fused with the 1-wide output layer and the backward seed dE/dz3 = (1/M) w3 celu'(z3)
-    {
+    if constexpr (ACT) {
       float es = 0.f;
 #pragma unroll
       for (int nt = 0; nt < NT3; nt++) {
@@ -518,9 +569,9 @@ __device__ __forceinline__ void g_tile(const GTileCtx& cx, const FusedProb& pr, 
     }
 
     // ---- B3: g2 = (W2^T g3) celu'(z2) over h2;  B2: g1 = (W1^T g2) celu'(z1) over h1 ----
-    g_product_inplace<NT3 / 2, NT2, NT3, P, W>(r, X3, X2, cx.a_bwd, inv_b3, cx.inv_alpha, N_B2, wave, lane16);
+    g_product_inplace<NT3 / 2, NT2, NT3, P, W, ACT>(r, X3, X2, cx.a_bwd, inv_b3, cx.inv_alpha, N_B2, wave, lane16);
     const int n_b1_first = g_b1_chunk_tiles(nt0, 0) * P;
-    g_product_inplace<NT2 / 2, NT1, NT2, P, W>(r, X2, X1, cx.a_bwd, inv_b2, cx.inv_alpha, n_b1_first, wave, lane16);
+    g_product_inplace<NT2 / 2, NT1, NT2, P, W, ACT>(r, X2, X1, cx.a_bwd, inv_b2, cx.inv_alpha, n_b1_first, wave, lane16);
     f32x4g (&G1)[NT1] = X1;
 
     // ---- B1: dE/dAEV = W0^T g1 in chunks of output tiles; members after the first of a work item add to what is there ----
@@ -531,19 +582,19 @@ __device__ __forceinline__ void g_tile(const GTileCtx& cx, const FusedProb& pr, 
       if (ci + 1 == nchunks) n_after = (m + 1 < cx.m1) ? N_F1 : 0;           // of the next member, or nothing
       if (ntc == 16) {
         f32x4g acc[16];
-        g_zero(acc);
-        g_b1_chunk<16, NT1 / 2, NT1, P, W>(r, G1, acc, cx.a_bwd, n_after, wave, lane16);
-        g_store_chunk<16>(acc, 16, grow, c0, acols, inv_b1, m > cx.m0);
+        if constexpr (ACT) g_zero(acc);
+        g_b1_chunk<16, NT1 / 2, NT1, P, W, ACT>(r, G1, acc, cx.a_bwd, n_after, wave, lane16);
+        if constexpr (ACT) g_store_chunk<16>(acc, 16, grow, c0, acols, inv_b1, m > cx.m0);
       } else if (ntc == 8) {
         f32x4g acc[8];
-        g_zero(acc);
-        g_b1_chunk<8, NT1 / 2, NT1, P, W>(r, G1, acc, cx.a_bwd, n_after, wave, lane16);
-        g_store_chunk<8>(acc, 8, grow, c0, acols, inv_b1, m > cx.m0);
+        if constexpr (ACT) g_zero(acc);
+        g_b1_chunk<8, NT1 / 2, NT1, P, W, ACT>(r, G1, acc, cx.a_bwd, n_after, wave, lane16);
+        if constexpr (ACT) g_store_chunk<8>(acc, 8, grow, c0, acols, inv_b1, m > cx.m0);
       } else {
         f32x4g acc[8];
-        g_zero(acc);
-        g_b1_tail<NT1 / 2, NT1, P, W>(r, G1, acc, ntc, cx.a_bwd, n_after, wave, lane16);
-        g_store_chunk<8>(acc, ntc, grow, c0, acols, inv_b1, m > cx.m0);
+        if constexpr (ACT) g_zero(acc);
+        g_b1_tail<NT1 / 2, NT1, P, W, ACT>(r, G1, acc, ntc, cx.a_bwd, n_after, wave, lane16);
+        if constexpr (ACT) g_store_chunk<8>(acc, ntc, grow, c0, acols, inv_b1, m > cx.m0);
       }
       c0 += ntc;
     }
@@ -569,13 +620,20 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fused16(FusedArgs G) {
     if (G.sched_items) {
       if (threadIdx.x == 0) {
         const int i = G.sched_off[blockIdx.x] + sched_pos;
-        s_tile = i < G.sched_off[blockIdx.x + 1] ? G.sched_items[i] : total;
+        s_tile = i < G.sched_off[blockIdx.x + 1] ? G.sched_items[i] : -1;
       }
       sched_pos++;
-    } else if (threadIdx.x == 0) s_tile = atomicAdd(G.counter, 1);
+    } else if (threadIdx.x == 0) {
+      const int i = atomicAdd(G.counter, 1);
+      s_tile = i < total ? i : -1;
+    }
     __syncthreads();
-    const int item = __builtin_amdgcn_readfirstlane(s_tile);
-    if (item >= total) break;
+    int item = __builtin_amdgcn_readfirstlane(s_tile);
+    if (item < 0) break;
+    // items [0, total): whole tiles; total + 2 i + hf: half hf of item i, run by the lower half of the waves (a static schedule
+    // may cut the items that would otherwise make up a last, mostly idle round of workgroups: fused_schedule_halves)
+    int hf = -1;
+    if (item >= total) { hf = (item - total) & 1; item = (item - total) >> 1; }
     const int t = item / per_tile;
     if (G.member_items) {
       cx.m0 = item - t * per_tile; cx.m1 = cx.m0 + 1;
@@ -585,12 +643,22 @@ __global__ __launch_bounds__(64 * W, 1) void mlp_fused16(FusedArgs G) {
     while (pi + 1 < G.nprob && t >= G.tile_start[pi + 1]) pi++;
     const FusedProb& pr = G.p[pi];
     const int tile = t - G.tile_start[pi];
-    // a tile without a single real row (the padding of a bucket's last 128 rows, seen by the 64-row form): nothing to do
-    if (pr.centre_of_row[tile * (16 * W)] < 0) continue;
-    switch (pr.shape) {
-      case 0: g_tile<16, 12, 10, P, W>(cx, pr, tile, wave, lane, ring, cst); break;
-      case 1: g_tile<12, 10, 8, P, W>(cx, pr, tile, wave, lane, ring, cst); break;
-      default: g_tile<10, 8, 6, P, W>(cx, pr, tile, wave, lane, ring, cst); break;
+    const int row0 = tile * (16 * W) + (hf > 0 ? 8 * W : 0);
+    // an item without a single real row (the padding of a bucket's last 128 rows): nothing to do
+    if (pr.centre_of_row[row0] < 0) continue;
+    const bool act = hf < 0 || wave < W / 2;
+    if (act) {
+      switch (pr.shape) {
+        case 0: g_tile<16, 12, 10, P, W, true>(cx, pr, row0, wave, lane, ring, cst); break;
+        case 1: g_tile<12, 10, 8, P, W, true>(cx, pr, row0, wave, lane, ring, cst); break;
+        default: g_tile<10, 8, 6, P, W, true>(cx, pr, row0, wave, lane, ring, cst); break;
+      }
+    } else {
+      switch (pr.shape) {
+        case 0: g_tile<16, 12, 10, P, W, false>(cx, pr, row0, wave, lane, ring, cst); break;
+        case 1: g_tile<12, 10, 8, P, W, false>(cx, pr, row0, wave, lane, ring, cst); break;
+        default: g_tile<10, 8, 6, P, W, false>(cx, pr, row0, wave, lane, ring, cst); break;
+      }
     }
   }
 }

@@ -63,3 +63,58 @@ def test_benchmark_case_packs_into_three_rounds():
     _, _, mk = _schedule([521, 261], [440.0, 296.0], 256)
     assert abs(mk - 3 * 440.0) < 1e-6
     assert _list_scheduling([521, 261], [440.0, 296.0], 256) > 3.3 * 440.0
+
+
+def _schedule_halves(count, cost, bins, mode, ratio=0.75):
+    lib = ani_hip.lib()
+    lib.ani_debug_fused_schedule_halves.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 5
+    count = np.ascontiguousarray(count, dtype=np.int32)
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    n = int(count.sum())
+    items = np.full(2 * max(n, 1), -1, dtype=np.int32)
+    off = np.zeros(bins + 1, dtype=np.int32)
+    split = np.zeros(len(count), dtype=np.int32)
+    nout = C.c_int()
+    mk = C.c_double()
+    rc = lib.ani_debug_fused_schedule_halves(len(count), count.ctypes.data, cost.ctypes.data, ratio, bins, mode, split.ctypes.data,
+                                             items.ctypes.data, off.ctypes.data, C.addressof(nout), C.addressof(mk))
+    assert rc == 0
+    return items[: nout.value], off, split, mk.value
+
+
+@pytest.mark.parametrize("count,cost,bins", [([521, 261], [440.0, 296.0], 256), ([261, 131], [440.0, 296.0], 256), ([66, 33], [440.0, 296.0], 256),
+                                             ([424, 216], [440.0, 296.0], 256), ([1], [5.0], 8), ([300, 200, 100, 7], [284.0, 284.0, 284.0, 91.0], 256),
+                                             ([5000, 3000], [440.0, 296.0], 256), ([3, 2, 9], [1.0, 7.5, 2.25], 4)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_schedule_with_half_items_covers_every_item_once(count, cost, bins, mode):
+    """Every item runs exactly once: whole, or as its two halves (ids n + 2 i + h); the halves are the LAST split[j] items of a type;
+    the searched split never makes the schedule longer than whole items only, and shortens the 50 001-atom case (261 + 131 tiles: five
+    costly tiles beyond one round) by more than a tenth."""
+    ratio = 0.75
+    items, off, split, mk = _schedule_halves(count, cost, bins, mode, ratio)
+    n = int(np.sum(count))
+    first = np.concatenate([[0], np.cumsum(count)])
+    whole = sorted(int(i) for i in items if i < n)
+    halves = sorted(int(i) - n for i in items if i >= n)
+    cut = sorted(halves[0::2])
+    assert halves == sorted([2 * (i // 2) + h for i in halves[0::2] for h in (0, 1)])      # both halves of every cut item
+    assert [i // 2 for i in cut] == [i for j in range(len(count)) for i in range(first[j + 1] - split[j], first[j + 1])]
+    assert sorted(whole + [i // 2 for i in cut]) == list(range(n))
+    assert off[0] == 0 and off[-1] == len(items) and np.all(np.diff(off) >= 0)
+    if mode == 0:
+        assert split.sum() == 0
+    if mode == 2:
+        assert np.array_equal(split, np.asarray(count))
+    # loads
+    type_of = np.repeat(np.arange(len(count)), count)
+    c = np.asarray(cost, dtype=float)
+
+    def item_cost(i):
+        return c[type_of[i]] if i < n else ratio * c[type_of[(i - n) // 2]]
+    loads = [sum(item_cost(int(i)) for i in items[off[b]:off[b + 1]]) for b in range(bins)]
+    assert max(loads) <= mk * (1 + 1e-9) + 1e-9
+    _, _, _, mk0 = _schedule_halves(count, cost, bins, 0, ratio)
+    if mode == 1:
+        assert mk <= mk0 * (1 + 1e-9)
+        if list(count) == [261, 131]:
+            assert mk < 0.9 * mk0 and split.sum() > 0

@@ -29,14 +29,16 @@ def _box(name):
     return hx.random_box(700, 7, 22.0, seed=9)
 
 
-FORMS = [(1, 128), (1, 64), (0, 0)]
+# (generation, rows per tile, halves): halves 2 = every item of the sixteen-row kernel runs as two half items (the lower half of
+# the waves does the rows, the upper half only its share of the loads and the rendezvous); 1 = where the schedule wants them
+FORMS = [(1, 128, 1), (1, 64, 1), (0, 0, 0), (1, 128, 2), (1, 64, 2)]
 
 
-@pytest.mark.parametrize("gen,rows", FORMS, ids=["rows16x8", "rows16x4", "rows32x4"])
+@pytest.mark.parametrize("gen,rows,halves", FORMS, ids=["rows16x8", "rows16x4", "rows32x4", "rows16x8-halves", "rows16x4-halves"])
 @pytest.mark.parametrize("mode", [2, 3], ids=["member-items", "members-in-sequence"])
 @pytest.mark.parametrize("arith", [1, 2], ids=["bf16x3", "f16x2"])
 @pytest.mark.parametrize("kind,nm,box", CASES, ids=[f"{k}-m{m}-{b}" for k, m, b in CASES])
-def test_fused_mlp_equals_per_layer_kernels(kind, nm, box, arith, mode, gen, rows, tmp_path):
+def test_fused_mlp_equals_per_layer_kernels(kind, nm, box, arith, mode, gen, rows, halves, tmp_path):
     """mode: mlp_fused 2 = small systems with several members run (tile, member) work items, each member writing its own
     dE/dAEV rows (summed by a second kernel); 3 = a tile's members one after the other in its workgroup."""
     if nm == 1 and mode == 3:
@@ -51,6 +53,7 @@ def test_fused_mlp_equals_per_layer_kernels(kind, nm, box, arith, mode, gen, row
         ani.set_option("mlp_arith", arith)
         ani.set_option("mlp_fused_gen", gen)
         ani.set_option("mlp_fused_rows", rows)
+        ani.set_option("mlp_fused_halves", halves)
         out[fused] = ani.compute(inp, ago=0)
         if fused:
             want = "mlp_fused<" if gen == 0 else ("mlp_fused16<%d, %d>" % (3 if arith == 1 else 2, 8 if rows == 128 else 4))
