@@ -265,7 +265,9 @@ int ani_debug_colmap(ani_handle* h, int* out);
  *   "mlp_fused_halves" (default 1; sixteen-row kernel): the static schedule of the fused launch may run an item as two HALF items (the
  *     lower half of a workgroup's waves takes 64 of the 128 rows, the upper half only its share of the loads; ~0.7 of the item's
  *     time each) where that shortens the launch -- the items beyond the last full round of workgroups otherwise make a round of
- *     their own with most of the chip idle.  0 = whole items only, 2 = every item as two halves (tests, measurements).
+ *     their own with most of the chip idle.  A split the cost model likes is timed against the whole items (three launches each,
+ *     once per set of tile counts, on the step that builds the schedule) and kept only if faster; results do not depend on the
+ *     choice.  0 = whole items only, 2 = every item as two halves (tests, measurements).
  *   "reuse_build_list_upload" (default 0; the LAMMPS adapter turns it on): the ani_compute_full call that follows an
  *     ani_build_list with the SAME coordinates pointer uses the positions that call uploaded instead of uploading them again.
  *     For callers whose array has not changed in between (the same timestep); a caller that might hand over another array at a

@@ -812,18 +812,68 @@ int compute_mlp_fused(ani_handle* h, hipStream_t st) {
                   12.0;   // MFMA blocks of a member + a little for what a tile costs whatever its size
         if (!G.member_items) cost[q] *= m.M;
       }
-      // the sixteen-row kernel takes half items: the schedule may cut the items of a last, mostly idle round in two.  A half costs
-      // kFusedHalfCost of its item (64 of 128 rows with all the weights streamed: measured, profiles/r04_mlp_halves.log)
+      // The sixteen-row kernel takes half items: the schedule may cut the items of a last, mostly idle round in two.  A half costs
+      // about kFusedHalfCost of its item (64 of 128 rows with all the weights streamed: profiles/r04_mlp_halves.log), and the
+      // cost model is good to about 5 %: a split the model likes by at least 3 % is TIMED against the whole items on this very
+      // step's rows (three launches each, the first not counted; the launch is idempotent) and kept only if it is faster --
+      // once per set of tile counts (ANI_FUSED_AUTOTUNE=0: no timing, a split needs 8 % by the model).
       std::vector<int> items((size_t)2 * std::max(nitems, 1)), off(bins + 1);
       int nsched = nitems;
       const int split_mode = !gen ? 0 : (h->mlp_fused_halves == 2 ? 2 : (sub != 2 ? h->mlp_fused_halves : 0));   // searched for 128-row tiles only
       static const double half_cost = [] { const char* e = getenv("ANI_FUSED_HALF_COST"); return e ? atof(e) : kFusedHalfCost; }();
-      (void)fused_schedule_halves(np, cnt, cost, half_cost, bins, split_mode, nullptr, items.data(), off.data(), &nsched);
-      HIP_TRY(h, h->fused_sched.reserve((size_t)nsched + bins + 1));
-      HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p, items.data(), sizeof(int) * (size_t)nsched, hipMemcpyHostToDevice, st));
-      HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p + nsched, off.data(), sizeof(int) * (size_t)(bins + 1), hipMemcpyHostToDevice, st));
-      HIP_TRY(h, hipStreamSynchronize(st));   // items / off are locals; once per re-neighbouring
-      h->sched_nitems = nsched;
+      static const bool autotune = [] { const char* e = getenv("ANI_FUSED_AUTOTUNE"); return !(e && atoi(e) == 0); }();
+      auto upload = [&](const std::vector<int>& it, int n) -> int {
+        HIP_TRY(h, h->fused_sched.reserve((size_t)2 * std::max(nitems, 1) + bins + 1));
+        HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p, it.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(h->fused_sched.p + n, off.data(), sizeof(int) * (size_t)(bins + 1), hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipStreamSynchronize(st));   // items / off are locals; once per re-neighbouring
+        h->sched_nitems = n;
+        return ANI_OK;
+      };
+      auto timed = [&](float* ms) -> int {   // the fused launch with the schedule just uploaded
+        G.sched_items = h->fused_sched.p; G.sched_off = h->fused_sched.p + h->sched_nitems; G.sched_blocks = bins;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIP_TRY(h, hipEventCreate(&e0));
+        HIP_TRY(h, hipEventCreate(&e1));
+        hipError_t err = launch_mlp_fused16(G, arith, 8, st);
+        if (err == hipSuccess) err = hipEventRecord(e0, st);
+        for (int k = 0; k < 2 && err == hipSuccess; k++) err = launch_mlp_fused16(G, arith, 8, st);
+        if (err == hipSuccess) err = hipEventRecord(e1, st);
+        if (err == hipSuccess) err = hipEventSynchronize(e1);
+        if (err == hipSuccess) err = hipEventElapsedTime(ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        HIP_TRY(h, err);
+        return ANI_OK;
+      };
+      std::vector<int> split(np, 0);
+      (void)fused_schedule_halves(np, cnt, cost, half_cost, bins, split_mode, split.data(), items.data(), off.data(), &nsched,
+                                  autotune && split_mode == 1 ? 0.03 : 0.08);
+      int any_split = 0;
+      for (int q = 0; q < np; q++) any_split += split[q];
+      {
+        const int rcu = upload(items, nsched);
+        if (rcu) return rcu;
+      }
+      if (autotune && split_mode == 1 && any_split && !getenv("ANI_FUSED_SPLIT")) {
+        float t_split = 0.f, t_whole = 0.f;
+        int rct = timed(&t_split);
+        if (rct) return rct;
+        std::vector<int> items_w((size_t)std::max(nitems, 1)), off_split = off;
+        int n_w = nitems;
+        (void)fused_schedule_halves(np, cnt, cost, half_cost, bins, 0, nullptr, items_w.data(), off.data(), &n_w);
+        rct = upload(items_w, n_w);
+        if (!rct) rct = timed(&t_whole);
+        if (rct) return rct;
+        if (t_split < t_whole) {   // the split stays: back it goes
+          off = off_split;
+          rct = upload(items, nsched);
+          if (rct) return rct;
+        }
+        if (getenv("ANI_FUSED_AUTOTUNE_VERBOSE"))
+          fprintf(stderr, "libani_hip: fused MLP schedule, %d items: whole %.4f ms, with half items %.4f ms per launch -> %s\n", nitems,
+                  t_whole / 2, t_split / 2, t_split < t_whole ? "halves" : "whole");
+      }
       h->sched_key[0] = total; h->sched_key[1] = per_tile; h->sched_key[2] = mix; h->sched_key[3] = bins;
     }
     G.sched_items = h->fused_sched.p;

@@ -152,7 +152,7 @@ int fused_num_cus();
 double fused_schedule(int nitem_types, const int* count, const double* cost, int bins, int* items_out, int* off_out);
 // the same with half items for the sixteen-row kernel (ids total + 2 i + h); see ani_kernels_mlpf.hip
 double fused_schedule_halves(int nitem_types, const int* count, const double* cost, double half_ratio, int bins, int split_mode,
-                             int* split_out, int* items_out, int* off_out, int* n_items_out);
+                             int* split_out, int* items_out, int* off_out, int* n_items_out, double min_gain = 0.08);
 // dst[i] = sum over m < M of parts[m * part_stride + i], i < n (n a multiple of 4, 16-byte aligned pointers)
 void launch_sum_parts(const float* parts, long long part_stride, int M, float* dst, long long n, hipStream_t st);
 // diagnostic builds (-DABLF_STAMPS) only: cycles per phase summed over tiles; returns 0 in the shipped build

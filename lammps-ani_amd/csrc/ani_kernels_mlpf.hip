@@ -856,11 +856,11 @@ double fused_schedule(int ntypes, const int* count, const double* cost, int bins
 // workgroup's waves at half_ratio of the item's cost -- more than half: the weights stream through the workgroup all the same).
 // The last split[j] items of type j are cut in two where that shortens the schedule: the items beyond the last full round of
 // workgroups otherwise make a round of their own with most of the chip idle.  split_mode 1: searched (a few candidate counts per
-// type, most expensive types first, two sweeps; kept only if the makespan falls by 8 % -- the cost model is good to about 5 %:
-// 10 002 atoms x 8 members, predicted 7 % shorter, measured 2.5 % longer), 2: every item (tests, measurements).
+// type, most expensive types first, two sweeps; kept only if the makespan falls by min_gain -- the cost model is good to about
+// 5 %: the caller either asks for 8 % or times the candidate against the whole items), 2: every item (tests, measurements).
 // items_out holds up to sum(count) + max splits entries.  Returns the makespan; *n_items_out = entries written.
 double fused_schedule_halves(int ntypes, const int* count, const double* cost, double half_ratio, int bins, int split_mode, int* split_out,
-                             int* items_out, int* off_out, int* n_items_out) {
+                             int* items_out, int* off_out, int* n_items_out, double min_gain) {
   std::vector<int> first(ntypes + 1, 0);
   for (int j = 0; j < ntypes; j++) first[j + 1] = first[j] + count[j];
   const int total = first[ntypes];
@@ -872,7 +872,15 @@ double fused_schedule_halves(int ntypes, const int* count, const double* cost, d
     return fused_pack(2 * ntypes, ecount.data(), ecost.data(), bins, take);
   };
   double T = makespan(split, best);
-  if (split_mode == 2) {
+  if (const char* e = getenv("ANI_FUSED_SPLIT")) {   // experiments: "k0,k1,..." = how many of each type's last items to cut
+    int j = 0;
+    for (const char* q = e; *q && j < ntypes; j++) {
+      split[j] = std::max(0, std::min(count[j], atoi(q)));
+      while (*q && *q != ',') q++;
+      if (*q == ',') q++;
+    }
+    T = makespan(split, best);
+  } else if (split_mode == 2) {
     for (int j = 0; j < ntypes; j++) split[j] = count[j];
     T = makespan(split, best);
   } else if (split_mode == 1) {
@@ -897,7 +905,7 @@ double fused_schedule_halves(int ntypes, const int* count, const double* cost, d
         }
         cur[j] = keep;
       }
-    if (Tc < 0.92 * T0) { split = cur; T = makespan(split, best); }
+    if (Tc < (1.0 - min_gain) * T0) { split = cur; T = makespan(split, best); }
     else T = makespan(split, best);
   }
   // numbering: type j's whole items first[j] .. first[j] + count[j] - split[j]; the halves of the split[j] items behind them

@@ -8,8 +8,9 @@ from lammps_ani_amd import ani_hip, harness as hx, model_file as mf
 
 dev = torch.device("cuda:0")
 variants = sys.argv[1:] or [""]
-cases = [("water-10002 x 8", "ani2x", False, hx.spatial_sort(hx.water_box(10002, seed=12345))),
-         ("CH4/O2-100008 x 8 + repulsion", "ani1x", True, hx.spatial_sort(hx.combustion_box(100008, seed=12345)))]
+cases = [("water-10002 x 8", "ani2x", False, hx.spatial_sort(hx.water_box(10002, seed=12345)))]
+if not os.environ.get("MEMBERS_PROBE_FIRST_ONLY"):
+    cases.append(("CH4/O2-100008 x 8 + repulsion", "ani1x", True, hx.spatial_sort(hx.combustion_box(100008, seed=12345))))
 for name, kind, rep, sysm in cases:
     path = f"/tmp/mp_{kind}.anim"
     mf.write_model(path, mf.synthetic_model(kind, 8, seed=2024, repulsion=rep))
