@@ -70,21 +70,3 @@ def test_the_timed_steps_carry_no_first_use_costs():
     allowance = 0.10 * d["md_loop"]["list_rebuilds"]          # ms per step that one re-neighbouring among 20 steps may add
     assert md < 1.25 * hot + 0.03 + allowance, (md, hot, d["md_loop"])
 
-
-def test_committed_counter_summary_belongs_to_the_committed_kernel_sources():
-    """bench.py fills `roofline.traffic` from profiles/<PMC_SUMMARY> only while the sha256 over lammps-ani_amd/csrc/* still is the
-    one the counters were collected on (tools/profile_round.sh): a source change without a new counter run would silently turn
-    the driver's bench line back to `traffic: null`.  CPU check of exactly that equality."""
-    import json
-    import os
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, root)
-    import bench
-    path = os.path.join(root, "profiles", bench.PMC_SUMMARY)
-    assert os.path.exists(path), f"profiles/{bench.PMC_SUMMARY} is missing"
-    summary = json.load(open(path))
-    assert summary["source_digest"] == bench.source_digest(), \
-        "lammps-ani_amd/csrc changed after the counters were collected: run tools/r4_evidence.sh on a GPU box and commit profiles/"
-    for kernel in ("ani::aev_backward_fast", "ani::aev_forward_fused", "ani::mlp_fused16"):
-        assert any(k.startswith(kernel) for k in summary["kernels"]), kernel

@@ -82,3 +82,22 @@ def test_two_rank_bench_on_one_card_takes_the_fallback_transport():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in d["roofline"], k
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
+
+
+def test_committed_counter_summary_belongs_to_the_committed_kernel_sources():
+    """bench.py fills `roofline.traffic` from profiles/<PMC_SUMMARY> only while the sha256 over lammps-ani_amd/csrc/* still is the
+    one the counters were collected on (tools/profile_round.sh): a source change without a new counter run would silently turn
+    the driver's bench line back to `traffic: null`.  CPU check of exactly that equality."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    path = os.path.join(root, "profiles", bench.PMC_SUMMARY)
+    assert os.path.exists(path), f"profiles/{bench.PMC_SUMMARY} is missing"
+    summary = json.load(open(path))
+    assert summary["source_digest"] == bench.source_digest(), \
+        "lammps-ani_amd/csrc changed after the counters were collected: run tools/r4_evidence.sh on a GPU box and commit profiles/"
+    for kernel in ("ani::aev_backward_fast", "ani::aev_forward_fused", "ani::mlp_fused16"):
+        assert any(k.startswith(kernel) for k in summary["kernels"]), kernel
